@@ -1,0 +1,261 @@
+"""CPU: pin the oracle (oracle/nast_oracle.py) against fixtures captured from the unmodified reference
+(oracle/gen_golden.py).  fp32 tolerance 1e-5 abs/rel unless stated; alignment indices exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from oracle import nast_oracle as O
+
+RT, AT = 2e-5, 2e-6
+
+
+def T(a):
+    t = torch.from_numpy(np.asarray(a))
+    return t
+
+
+def W(g, prefix):
+    return {k: T(v).clone() for k, v in sub(g, prefix).items()}
+
+
+def close(a, b, rtol=RT, atol=AT):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def leaf(w):
+    for v in w.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    return w
+
+
+def check_grads(w, gold, prefix="", rtol=2e-4, atol=2e-6):
+    n = 0
+    for k, gv in gold.items():
+        assert w[prefix + k].grad is not None, k
+        close(w[prefix + k].grad, gv, rtol, atol)
+        n += 1
+    assert n > 0
+
+
+def test_layers():
+    g = load_golden("g1_layers")
+    x, mem = T(g["in/x"]).requires_grad_(True), T(g["in/mem"]).requires_grad_(True)
+    masks = {"self_pad": T(g["in/pad_self"]), "cross_pad": T(g["in/pad_mem"]), "self_causal": T(g["in/causal"])}
+    for tag in ("self_pad", "cross_pad", "self_causal"):
+        w = leaf(W(g, "w/mha/"))
+        kv = mem if tag == "cross_pad" else x
+        y = O.attention(w, "", x, kv, masks[tag], 4)
+        close(y, g[f"out/mha/{tag}/y"])
+        x.grad = None; mem.grad = None
+        (y * T(g[f"in/mha/{tag}/R"])).sum().backward()
+        close(x.grad, g[f"g/mha/{tag}/x"], 2e-4)
+        check_grads(w, sub(g, f"g/mha/{tag}/w/"))
+    w = leaf(W(g, "w/enc/"))
+    y = O.encoder_layer(w, "", x, masks["self_pad"], 4)
+    close(y, g["out/enc/y"])
+    x.grad = None
+    (y * T(g["in/enc/R"])).sum().backward()
+    close(x.grad, g["g/enc/x"], 2e-4)
+    check_grads(w, sub(g, "g/enc/w/"))
+    for tag, tm in (("pad", masks["self_pad"]), ("causal", masks["self_causal"])):
+        w = leaf(W(g, "w/dec/"))
+        y = O.decoder_layer(w, "", x, mem, masks["cross_pad"], tm, 4)
+        close(y, g[f"out/dec/{tag}/y"])
+        x.grad = None; mem.grad = None
+        (y * T(g[f"in/dec/{tag}/R"])).sum().backward()
+        close(x.grad, g[f"g/dec/{tag}/x"], 2e-4)
+        close(mem.grad, g[f"g/dec/{tag}/mem"], 2e-4)
+        check_grads(w, sub(g, f"g/dec/{tag}/w/"))
+
+
+def _cfg(g, **over):
+    kw = dict(V=int(g["cfg/V"]), d=int(g["cfg/d"]), h=int(g["cfg/h"]), N=int(g["cfg/N"]), L=int(g["cfg/L"]))
+    if "cfg/learnable" in g:
+        kw["learnable"] = bool(g["cfg/learnable"])
+    if "cfg/disc" in g:
+        kw["disc"] = str(g["cfg/disc"])
+    kw.update(over)
+    return O.Cfg(**kw)
+
+
+@pytest.mark.parametrize("tag", ["simple", "learnable"])
+def test_style_transformer(tag):
+    g = load_golden(f"g2_style_transformer_{tag}")
+    cfg = _cfg(g)
+    src, sl, gold, gl, style = (T(g[k]) for k in ("in/src", "in/src_len", "in/gold", "in/gold_len", "in/style"))
+
+    def fresh():
+        return leaf({"model_F." + k: v for k, v in W(g, "w/").items()})
+
+    # teacher-forced, hard tokens
+    w = fresh()
+    lp, tl, ll, ge, ap = O.style_transformer(w, cfg, src, sl, gold, gl, style, False, 1.0, True)
+    close(lp, g["out/teacher_hard/log_probs"], 1e-4, 1e-5)
+    loss = (lp * T(g["in/teacher_hard/R"])).sum()
+    if cfg.learnable:
+        close(ll, g["out/teacher_hard/length_loss"], 1e-4, 1e-5)
+        close(ge, g["out/teacher_hard/gen_err"])
+        assert np.array_equal(tl.numpy(), g["out/teacher_hard/tgt_lengths"])
+        loss = loss + (ll * T(g["in/teacher_hard/W"])).sum()
+    loss.backward()
+    check_grads(w, sub(g, "g/teacher_hard/"), "model_F.", 5e-4, 5e-6)
+    lp = O.style_transformer(fresh(), cfg, src, sl, gold, gl, style, False, 0.7, True)[0]
+    close(lp, g["out/teacher_hard_t07/log_probs"], 1e-4, 1e-5)
+
+    # teacher-forced, soft tokens
+    w = fresh()
+    soft = T(g["in/teacher_soft/soft"]).requires_grad_(True)
+    lp, tl, ll, ge, ap = O.style_transformer(w, cfg, soft, sl, gold, gl, style, False, 1.0, True)
+    close(lp, g["out/teacher_soft/log_probs"], 1e-4, 1e-5)
+    loss = (lp * T(g["in/teacher_soft/R"])).sum()
+    if cfg.learnable:
+        close(ll, g["out/teacher_soft/length_loss"], 1e-4, 1e-5)
+        loss = loss + (ll * T(g["in/teacher_soft/W"])).sum()
+    loss.backward()
+    close(soft.grad, g["gx/teacher_soft/soft"], 5e-4, 5e-6)
+    check_grads(w, sub(g, "g/teacher_soft/"), "model_F.", 5e-4, 5e-6)
+
+    # generate
+    w = fresh()
+    lp, tl, _, _, ap = O.style_transformer(w, cfg, gold, gl, None, None, 1 - style, True, 1.0, True)
+    close(lp, g["out/generate/log_probs"], 1e-4, 1e-5)
+    if cfg.learnable:
+        assert np.array_equal(tl.numpy(), g["out/generate/tgt_lengths"])
+        assert np.array_equal(ap.numpy(), g["out/generate/allpos"])
+    (lp * T(g["in/generate/R"])).sum().backward()
+    check_grads(w, sub(g, "g/generate/"), "model_F.", 5e-4, 5e-6)
+
+    if cfg.learnable:
+        w = fresh()
+        out = O.style_transformer(w, cfg, gold, gl, gold, gl, style, False, 1.0, False)
+        close(out[0], g["out/teacher_noz/log_probs"], 1e-4, 1e-5)
+        # HiddenDecoder forward (no final LN) vs incremental (final LN)
+        wl = {k[len("model_F.length_predictor.decoder."):]: v for k, v in w.items() if k.startswith("model_F.length_predictor.decoder.")}
+        x, mem, sm = T(g["in/hd/x"]), T(g["in/hd/mem"]), T(g["in/hd/smask"])
+        n = x.shape[1]
+        causal = (torch.ones(n, n).tril() == 0).view(1, 1, n, n)
+        with torch.no_grad():
+            close(O.decoder_stack(wl, "", x, mem, sm, causal, cfg.h, 3), g["out/hd/forward"], 1e-4, 1e-5)
+            close(O.hidden_decoder_incremental(wl, "", x, mem, sm, cfg.h), g["out/hd/incremental"], 1e-4, 1e-5)
+
+
+def test_match_golden():
+    g = load_golden("g6_match")
+    for name in g["cases"]:
+        name = str(name)
+        ap = O.viterbi_align(g[f"{name}/cost0"], g[f"{name}/cost"], g[f"{name}/src_len"], g[f"{name}/tgt_len"])
+        assert np.array_equal(ap, g[f"{name}/allpos"]), name
+        # end-to-end (cost recomputed by the oracle) must agree as well on this platform
+        w = {"token_embed.weight": T(g[f"{name}/embed"])}
+        src = T(g[f"{name}/src_soft"]) if f"{name}/src_soft" in g else T(g[f"{name}/src"])
+        ap2 = O.match(w, "", src, T(g[f"{name}/src_len"]), T(g[f"{name}/tgt"]), T(g[f"{name}/tgt_len"]))
+        assert np.array_equal(ap2.numpy(), g[f"{name}/allpos"]), name
+    assert g["insdel/allpos"].tolist() == [[0, 1, 1, 2, 2, 4, 5, 6]]
+    assert g["identity/allpos"].tolist() == [[0, 1, 2, 3, 4, 5, 6, 7]]
+
+
+def test_gumbel_family():
+    g = load_golden("g7_gumbel")
+    logits = T(g["in/logits"])
+    for name in ("gumbel_max", "gumbel_max_tau"):
+        x = logits.clone().requires_grad_(True)
+        ret, ys = O.gumbel_max(x, T(g[f"in/{name}/E"]), float(g[f"in/{name}/tau"]))
+        close(ret, g[f"out/{name}/ret"], 1e-5, 1e-6)
+        close(ys, g[f"out/{name}/y_soft"])
+        (ret * T(g[f"in/{name}/R_ret"])).sum().backward(retain_graph=True)
+        close(x.grad, g[f"g/{name}/from_ret"], 1e-4, 1e-6)
+        x.grad = None
+        (ys * T(g[f"in/{name}/R_soft"])).sum().backward()
+        close(x.grad, g[f"g/{name}/from_soft"], 1e-4, 1e-6)
+    x = logits.clone().requires_grad_(True)
+    y = O.gumbel_softmax(x, T(g["in/gumbel_softmax/E"]), 0.8)
+    close(y, g["out/gumbel_softmax/y"])
+    (y * T(g["in/gumbel_softmax/R"])).sum().backward()
+    close(x.grad, g["g/gumbel_softmax/x"], 1e-4, 1e-6)
+    x = logits.clone().requires_grad_(True)
+    y = O.gumbel_max_with_mask(x, T(g["in/gumbel_max_with_mask/mask"]), T(g["in/gumbel_max_with_mask/E"]))
+    close(y, g["out/gumbel_max_with_mask/y"], 1e-5, 1e-6)
+    (y * T(g["in/gumbel_max_with_mask/R"])).sum().backward()
+    close(x.grad, g["g/gumbel_max_with_mask/x"], 1e-4, 1e-6)
+    for allow in (0, 1):
+        x = logits.clone().requires_grad_(True)
+        yh, ys = O.straight_max(x, bool(allow))
+        close(yh, g[f"out/straight_max_{allow}/y_hard"], 1e-5, 1e-6)
+        close(ys, g[f"out/straight_max_{allow}/y_soft"])
+        if allow:
+            (yh * T(g["in/straight_max_1/R"])).sum().backward()
+            close(x.grad, g["g/straight_max_grad/x"], 1e-4, 1e-6)
+    close(O.onehot(T(g["in/onehot/sent"]), logits.shape[-1]), g["out/onehot/y"])
+
+
+@pytest.mark.parametrize("disc", ["cond", "multi"])
+def test_discriminator(disc):
+    g = load_golden(f"g8_discriminator_{disc}")
+    cfg = _cfg(g)
+    tok, tl = T(g["in/tok"]), T(g["in/len"])
+    style = T(g["in/style"]) if "in/style" in g else None
+    w = leaf({"model_D." + k: v for k, v in W(g, "w/").items()})
+    lp = O.discriminator(w, cfg, tok, tl, style)
+    close(lp, g["out/hard/log_probs"], 1e-4, 1e-5)
+    (lp * T(g["in/hard/R"])).sum().backward()
+    check_grads(w, sub(g, "g/hard/"), "model_D.", 5e-4, 5e-6)
+    w = leaf({"model_D." + k: v for k, v in W(g, "w/").items()})
+    soft = T(g["in/soft/soft"]).requires_grad_(True)
+    lp = O.discriminator(w, cfg, soft, tl, style)
+    close(lp, g["out/soft/log_probs"], 1e-4, 1e-5)
+    (lp * T(g["in/soft/R"])).sum().backward()
+    close(soft.grad, g["gx/soft/soft"], 5e-4, 5e-6)
+    check_grads(w, sub(g, "g/soft/"), "model_D.", 5e-4, 5e-6)
+
+
+def check_step_state(w, grads, g, s, pref, rtol=1e-3):
+    """Post-step gradients (clipped) and weights.  Adam's first steps move a weight by
+    lr*g/(|g|+1e-8): where |g| is at rounding-noise level (e.g. key-projection biases, whose exact
+    gradient is 0) the update is ill-conditioned, so those elements only get the |dw| <= lr bound."""
+    gold_g = sub(g, s + "g/")
+    gscale = max(float(np.abs(v).max()) for v in gold_g.values())
+    for k, v in sub(g, s + "w/").items():
+        if not k.startswith(pref):
+            continue
+        short = k[len(pref):]
+        wv = w[k].detach().numpy()
+        if short in gold_g:
+            gg = gold_g[short]
+            np.testing.assert_allclose(grads[k].numpy(), gg, rtol=rtol, atol=2e-6 * gscale)
+            solid = np.abs(gg) > 1e-4 * gscale
+            np.testing.assert_allclose(wv[solid], v[solid], rtol=1e-4, atol=3e-6)
+            np.testing.assert_allclose(wv, v, rtol=0, atol=2.5e-4)
+        else:
+            np.testing.assert_allclose(wv, v, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["simple", "learnable"])
+@pytest.mark.parametrize("mode", ["f_step", "d_step", "f_step_pretrain"])
+def test_steps(tag, mode):
+    g = load_golden(f"g9_{tag}_{mode}")
+    cfg = _cfg(g)
+    w0 = {k: v for k, v in W(g, "w0/").items() if k.startswith("model_")}
+    tr = O.Trainer(w0, cfg)
+    for step in range(2):
+        s = f"s{step}/"
+        sent, sl, dom = T(g[s + "in/sent"]), T(g[s + "in/sent_length"]), T(g[s + "in/domain"])
+        E = [T(g[s + f"in/E{i}"]) for i in range(int(g[s + "in/nE"]))]
+        if mode == "d_step":
+            ret = (tr.d_step(sent, sl, dom, E),)
+        else:
+            ret = tr.f_step(sent, sl, dom, T(g[s + "in/noise_tok"]), T(g[s + "in/noise_len"]), E,
+                            cyc_rec_enable=(mode == "f_step"))
+        np.testing.assert_allclose(np.asarray(ret, dtype=np.float64), g[s + "out/ret"], rtol=2e-4, atol=1e-5)
+        if float(g[s + "out/grad_norm"]) >= 0:
+            np.testing.assert_allclose(tr.last_norm, float(g[s + "out/grad_norm"]), rtol=2e-4)
+        pref = "model_D." if mode == "d_step" else "model_F."
+        check_step_state(tr.w, tr.last_grads, g, s, pref)
+
+
+def test_misc():
+    g = load_golden("g10_misc")
+    assert np.array_equal(O.get_lengths(T(g["get_lengths/in"]), 2).numpy(), g["get_lengths/out"])
+    close(O.generate_mask(5, g["generateMask/len"]), g["generateMask/out"])
