@@ -1,0 +1,220 @@
+/* nast_hip.h -- C-ABI of libnast_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * NAST-StyTrans generator training step.
+ *
+ * The reference (thu-coai/NAST) has no FFI: its hot path is a chain of PyTorch ATen calls inside
+ * styletransformer/transformer.py, styletransformer/seq2seq.py and utils/gumbel.py.  Each entry point
+ * below replaces one such chain (cited as file:line under /root/reference); the Python modules in
+ * nast_amd/ keep the reference's nn.Module surface and call these through ctypes.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (fp32 unless the name says otherwise), plain row-major;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream;
+ *   - no entry point allocates, frees or synchronises (graph-capture safe) unless documented;
+ *   - return value: 0 = ok, negative = NAST_E* below; nast_last_error() gives a message.
+ */
+#ifndef NAST_HIP_H
+#define NAST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAST_OK 0
+#define NAST_EINVAL (-1)   /* bad shape / pointer / unsupported size */
+#define NAST_ELAUNCH (-2)  /* hipLaunch / runtime error */
+
+const char* nast_last_error(void);
+int nast_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Grouped fp32 GEMM on MFMA (v_mfma_f32_32x32x2_f32), fused epilogue.
+ *   C = alpha * sum_{s<nsrc} op(A[s]) * op(B[s])  (+bias[n]) (+residual) (ReLU) (mask by relu_src>0)
+ * Replaces: nn.Linear / torch.matmul / addmm chains -- transformer.py:229 (soft-token x embedding),
+ * :280-294 (QKV + fc projections), :308-316 (FFN), :211-214 (generator projection), :390-392 and
+ * their autograd backward (dgrad: op = NN, wgrad: op = TN).
+ * Up to NAST_GEMM_MAX_GROUP independent problems run in ONE launch so that small projections fill
+ * the 256 CUs together.
+ * ---------------------------------------------------------------------------------------------- */
+#define NAST_GEMM_MAX_GROUP 8
+#define NAST_GEMM_MAX_SRC 3
+#define NAST_GEMM_RELU 1        /* C = max(C, 0) after bias/residual                                 */
+#define NAST_GEMM_ATOMIC 2      /* C += result with fp32 atomics (C pre-initialised); enables split-K */
+#define NAST_GEMM_ACCUM 4       /* C += result, non-atomic (single writer, no split-K)               */
+
+typedef struct nast_gemm_desc {
+  const float* A[NAST_GEMM_MAX_SRC]; /* op(A) is M x K.  transA=0: A stored [M, lda>=K]; transA=1: [K, lda>=M] */
+  const float* B[NAST_GEMM_MAX_SRC]; /* op(B) is K x N.  transB=0: B stored [K, ldb>=N]; transB=1: [N, ldb>=K] */
+  float* C;                          /* [M, ldc>=N]                                                            */
+  const float* bias;                 /* [N] or NULL                                                            */
+  const float* residual;             /* [M, ldc] or NULL, added after bias                                     */
+  const float* relu_src;             /* [M, ldc] or NULL: C = relu_src > 0 ? C : 0 (ReLU backward)             */
+  float* colsum;                     /* [M] or NULL: with transA=1, colsum[m] (+)= sum_k op(A[0])[m,k]  (bias grad) */
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  int32_t transA, transB;
+  int32_t nsrc;                      /* 1..3 products accumulated into the same C (all share M,N,K,ld*,trans*) */
+  int32_t flags;
+  float alpha;
+} nast_gemm_desc;
+
+int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (eps as given, reference uses 1e-6), one wavefront per row.
+ * Replaces: nn.LayerNorm in SublayerConnection / Encoder.norm / Decoder.norm -- transformer.py:324-330,
+ * :171, :188, :348-350.
+ * Row map: output row r reads input row  (r / grp) * grp_stride + grp_off + r % grp   (grp = 0: identity).
+ * Used to normalise only the rows a consumer needs (generator skips row 0, transformer.py:103;
+ * discriminator reads row 0 only, transformer.py:151).
+ * ---------------------------------------------------------------------------------------------- */
+int nast_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
+                           float* mean, float* rstd, int rows_out, int d, float eps,
+                           int grp, int grp_stride, int grp_off, void* stream);
+/* dx is [rows_in, d] and is fully written (rows not selected by the map get 0);
+ * dx_add (may be NULL, only with grp == 0): dx = LN-gradient + dx_add  (the residual branch of
+ * SublayerConnection, transformer.py:326, fused so that no separate add kernel runs);
+ * dgamma/dbeta [d] are ACCUMULATED (+=, fp32 atomics) -- caller zero-initialises or passes .grad. */
+int nast_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                           const float* rstd, float* dx, float* dgamma, float* dbeta, const float* dx_add,
+                           int rows_out, int rows_in, int d,
+                           int grp, int grp_stride, int grp_off, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused masked multi-head attention for short sequences (LDS-staged, whole K/V of one (batch, head)
+ * per workgroup).  Replaces: scaled_attention + the view/transpose/contiguous around it --
+ * transformer.py:287-303.
+ * q [B, nq, h*dk] (row stride ldq), k/v [B, nk, h*dk] (row strides ldk/ldv), out [B, nq, h*dk] (ldo).
+ * mask: uint8/bool, element (b, i, j) at mask[b*mask_bs + i*mask_qs + j], nonzero = masked (-inf);
+ *       key-padding masks use mask_qs = 0, the causal mask uses mask_bs = 0; NULL = no mask.
+ * lse  [B, h, nq] (log-sum-exp of the scaled, masked scores) is saved for backward.
+ * Limits: dk == 64 or dk <= 64 multiple of 4; nk <= 256.
+ * ---------------------------------------------------------------------------------------------- */
+int nast_mha_fwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask,
+                     float* out, float* lse, int B, int h, int nq, int nk, int dk,
+                     int ldq, int ldk, int ldv, int ldo, int64_t mask_bs, int64_t mask_qs,
+                     float scale, void* stream);
+int nast_mha_bwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask,
+                     const float* out, const float* dout, const float* lse,
+                     float* dq, float* dk_, float* dv, int B, int h, int nq, int nk, int dk,
+                     int ldq, int ldk, int ldv, int ldo, int64_t mask_bs, int64_t mask_qs,
+                     float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row kernels over the vocabulary axis (HBM-bound): one workgroup per row.
+ * Row addressing for x / y:  row r lives at  base + (r / grp) * grp_stride + (r % grp) * ld   (grp = 0:
+ * base + r * ld), so sliced views such as log_probs[:, 1:] need no copy.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nast_rows {
+  int64_t ld;          /* elements between consecutive rows inside a group */
+  int64_t grp;         /* rows per group (0 = flat)                        */
+  int64_t grp_stride;  /* elements between groups                          */
+} nast_rows;
+
+/* y = log_softmax(x * inv_temp).  Replaces Generator.forward, transformer.py:213-214. In place allowed. */
+int nast_log_softmax_fwd_f32(const float* x, nast_rows xr, float* y, nast_rows yr, int rows, int V,
+                             float inv_temp, void* stream);
+/* gx = (gy - exp(y) * sum(gy)) * inv_temp */
+int nast_log_softmax_bwd_f32(const float* gy, nast_rows gyr, const float* y, nast_rows yr,
+                             float* gx, nast_rows gxr, int rows, int V, float inv_temp, void* stream);
+/* Gumbel-softmax sample, utils/gumbel.py:9-69:
+ *   g = min(-log(E), 1e10), z = (logits + g) * inv_tau, (mask==0 -> z = -1e9), y = softmax(z), idx = argmax(y)
+ * E: the Exp(1) draw (injected noise, parity mode) or NULL -> in-kernel Philox4x32-10 keyed by (seed, offset).
+ * mask: int64 [rows, V] or NULL (gumbel_max_with_mask).  idx: int64 [rows] or NULL.
+ * noise_off==1 disables the noise (straight_max: softmax(logits)).                                   */
+int nast_gumbel_softmax_fwd_f32(const float* logits, nast_rows lr, const float* E, nast_rows er,
+                                const int64_t* mask, float* y, nast_rows yr, int64_t* idx,
+                                int rows, int V, float inv_tau, uint64_t seed, uint64_t offset,
+                                int noise_off, void* stream);
+/* gx = y * (gy - sum(gy * y)) * inv_tau   (softmax Jacobian) */
+int nast_softmax_bwd_f32(const float* gy, nast_rows gyr, const float* y, nast_rows yr,
+                         float* gx, nast_rows gxr, int rows, int V, float inv_tau, void* stream);
+/* Seq2seq.get_lengths, seq2seq.py:545-549: first eos index + 1, capped at L. tokens int64 [B, L]. */
+int nast_first_eos_length_i64(const int64_t* tokens, int64_t* lengths, int B, int L, int64_t eos, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding assembly: out[b, e + i, :] = tok(b, i) + pos[i],  out[b, 0..e-1, :] = extra rows.
+ * Replaces: torch.cat((style_emb, embed(tokens, pos)), 1) -- transformer.py:63-65, :141-148, :225-231.
+ *   tok(b,i) = tok_weight[ids[b,i]]  (ids != NULL)   or   tok_rows[b*L + i]  (soft tokens: GEMM output).
+ *   extra row j (j < n_extra <= 2) = extra_w[j][ extra_idx[j] ? extra_idx[j][b] : 0 ].
+ * Backward ACCUMULATES with fp32 atomics into d_tok_weight / d_pos / d_extra_w (caller zero-inits or
+ * passes .grad) and writes d_tok_rows [B*L, d] densely when soft tokens were used.
+ * ---------------------------------------------------------------------------------------------- */
+int nast_embed_fwd_f32(float* out, int B, int L, int d, int n_extra,
+                       const int64_t* ids, const float* tok_weight, const float* tok_rows,
+                       const float* pos_weight,
+                       const float* extra_w0, const int64_t* extra_idx0,
+                       const float* extra_w1, const int64_t* extra_idx1, void* stream);
+int nast_embed_bwd_f32(const float* dout, int B, int L, int d, int n_extra,
+                       const int64_t* ids, float* d_tok_weight, float* d_tok_rows,
+                       float* d_pos_weight,
+                       float* d_extra_w0, const int64_t* extra_idx0,
+                       float* d_extra_w1, const int64_t* extra_idx1, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Learnable alignment (LengthPredictor.match, transformer.py:394-449).
+ * ---------------------------------------------------------------------------------------------- */
+/* cost0[b,i] = |t_i|^2 + 1e-6 ; cost[b,i,s] = (sqrt(sum_c (t_i[c]-o_s[c])^2))^2   (transformer.py:411-412)
+ *   t_i = E[tgt_ids[b,i]];
+ *   o_s = E[src_ids[b,s]] with unk -> id 0 (hard source, :396-399)            when src_ids != NULL
+ *       = src_emb[b,s] + src_unk_w[(b*S+s)*src_unk_stride] * (E[0] - E[unk])   (soft source, :401-403)   */
+int nast_align_cost_f32(const float* E, int V, int d, const int64_t* tgt_ids, const int64_t* src_ids,
+                        const float* src_emb, const float* src_unk_w, int64_t src_unk_stride,
+                        int64_t unk_id, float* cost0, float* cost, int B, int T, int S, void* stream);
+/* Min-plus Viterbi DP over monotone alignments with skips {0,1,2,3} + backtrack; one wavefront per
+ * sentence, lane = source position, __shfl_up for f[s-1..s-3].  Bit-exact w.r.t. the reference given the
+ * same cost/cost0.  allpos int64 [B, T+1] (leading 0 for the style token, positions shifted by +1).
+ * Limits: S <= 256, T <= 256.                                                                          */
+int nast_align_viterbi_f32(const float* cost0, const float* cost, const int64_t* origin_length,
+                           const int64_t* target_length, int64_t* allpos, int B, int T, int S, void* stream);
+/* Extension with NO counterpart in the reference ("parity unpinned"): soft (log-sum-exp) version of the
+ * same recurrence, value = -tau * log sum_paths exp(-cost(path)/tau), forward + backward (posterior
+ * edge marginals = d value / d cost).  tau -> 0 recovers the Viterbi value.                            */
+int nast_align_lse_fwd_f32(const float* cost0, const float* cost, const int64_t* origin_length,
+                           const int64_t* target_length, float tau, float* value, float* alpha,
+                           int B, int T, int S, void* stream);
+int nast_align_lse_bwd_f32(const float* cost0, const float* cost, const int64_t* origin_length,
+                           const int64_t* target_length, float tau, const float* value, const float* alpha,
+                           const float* dvalue, float* dcost0, float* dcost, int B, int T, int S, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LengthPredictor glue (transformer.py:466-519 teacher-forced, :527-582 greedy decode).
+ * ---------------------------------------------------------------------------------------------- */
+/* cand(b,p) = origin_input[b,p] if p == 0 or (p < S1 and p-1 < len[b]) else eos            (:471-473)
+ * out[b,t,:] = (use_stay && allpos[b,t]==allpos[b,t-1]) ? unk : cand(b, allpos[b,t] + shift)   (:488-491, :504-505)
+ *              (+ pos_weight[t] when pos_weight != NULL, :493).  origin_input [B,S1,d], allpos int64 [B,T1].   */
+int nast_lp_gather_fwd_f32(const float* origin_input, const int64_t* origin_length, const int64_t* allpos,
+                           const float* eos, const float* unk, const float* pos_weight,
+                           float* out, int B, int S1, int T1, int d, int shift, int use_stay, void* stream);
+/* scatter-add (fp32 atomics) of d(out) into d_origin_input [B,S1,d] (may be NULL), d_eos [d], d_unk [d],
+ * d_pos [T1,d] (may be NULL; pos_skip_row0: row 0 gets no gradient, nn.Embedding padding_idx=0, :385). */
+int nast_lp_gather_bwd_f32(const float* dout, const int64_t* origin_length, const int64_t* allpos,
+                           float* d_origin_input, float* d_eos, float* d_unk, float* d_pos,
+                           int B, int S1, int T1, int d, int shift, int use_stay, int pos_skip_row0, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser side (seq2seq.py:536-537, :637-638): multi-tensor L2 norm + clip + Adam in few launches.
+ * ptrs are device arrays of device pointers (one entry per parameter tensor), sizes int64 element counts.
+ * ---------------------------------------------------------------------------------------------- */
+int nast_multi_sqnorm_f32(const float* const* grads, const int64_t* sizes, int n, float* out_sq /*[1], +=*/,
+                          void* stream);
+int nast_multi_adam_f32(float* const* params, float* const* grads /* scaled in place by the clip */, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* sizes, int n,
+                        const float* total_sqnorm /*device [1] or NULL*/, float max_norm,
+                        float lr, float beta1, float beta2, float eps, float weight_decay,
+                        float bias_c1, float bias_c2, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * In-library kernel timing (HIP events on the caller's stream) for bench.py's roofline block.
+ * nast_prof_begin(kind) arms timing of every subsequent launch of that kernel family
+ * (kind: 1 = gemm); nast_prof_end() synchronises the events and reports totals.
+ * Not graph-capture safe while armed.
+ * ---------------------------------------------------------------------------------------------- */
+int nast_prof_begin(int kind);
+int nast_prof_end(double* total_ms, double* total_flops, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAST_HIP_H */

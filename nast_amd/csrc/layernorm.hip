@@ -1,0 +1,146 @@
+// LayerNorm forward / backward, one 64-wide wavefront per row (d <= 1024 -> <= 16 values per lane,
+// kept in registers; HBM-bound: 8d bytes/row forward).
+#include "common.h"
+
+#define LN_MAX_PER_LANE 16
+
+__device__ __forceinline__ int64_t ln_in_row(int r, int grp, int grp_stride, int grp_off) {
+  return grp > 0 ? (int64_t)(r / grp) * grp_stride + grp_off + (r % grp) : r;
+}
+
+__global__ __launch_bounds__(256) void nast_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd,
+                                                          int rows_out, int d, float eps, int grp, int grp_stride, int grp_off) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows_out) return;
+  const float* xr = x + ln_in_row(r, grp, grp_stride, grp_off) * d;
+  float v[LN_MAX_PER_LANE];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < d ? xr[c] : 0.f;
+    s += v[i];
+  }
+  const float mu = wave_sum(s) / d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    const float t = c < d ? v[i] - mu : 0.f;
+    q += t * t;
+  }
+  const float rs = rsqrtf(wave_sum(q) / d + eps);
+  float* yr = y + (int64_t)r * d;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d) yr[c] = (v[i] - mu) * rs * gamma[c] + beta[c];
+  }
+  if (lane == 0) {
+    mean[r] = mu;
+    rstd[r] = rs;
+  }
+}
+
+__global__ __launch_bounds__(256) void nast_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ dx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          const float* __restrict__ dx_add,
+                                                          int rows_out, int d, int grp, int grp_stride, int grp_off) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][4][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float gam[LN_MAX_PER_LANE], ag[LN_MAX_PER_LANE], ab[LN_MAX_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    gam[i] = c < d ? gamma[c] : 0.f;
+    ag[i] = 0.f;
+    ab[i] = 0.f;
+  }
+  for (int r = blockIdx.x * 4 + wave; r < rows_out; r += gridDim.x * 4) {
+    const int64_t ir = ln_in_row(r, grp, grp_stride, grp_off);
+    const float* xr = x + ir * d;
+    const float* gr = dy + (int64_t)r * d;
+    const float mu = mean[r], rs = rstd[r];
+    float xh[LN_MAX_PER_LANE], g[LN_MAX_PER_LANE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = c < d;
+      const float dyv = ok ? gr[c] : 0.f;
+      xh[i] = ok ? (xr[c] - mu) * rs : 0.f;
+      g[i] = dyv * gam[i];
+      s1 += g[i];
+      s2 += g[i] * xh[i];
+      ag[i] += dyv * xh[i];
+      ab[i] += dyv;
+    }
+    s1 = wave_sum(s1) / d;
+    s2 = wave_sum(s2) / d;
+    float* dxr = dx + ir * d;
+    const float* addr = dx_add ? dx_add + ir * d : nullptr;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+      const int c = lane + 64 * i;
+      if (c < d) dxr[c] = rs * (g[i] - s1 - xh[i] * s2) + (addr ? addr[c] : 0.f);
+    }
+  }
+  // cross-wave reduction of the parameter gradients, then one atomic per column per workgroup
+  float* rg = red;
+  float* rb = red + 4 * d;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    if (c < d) {
+      rg[wave * d + c] = ag[i];
+      rb[wave * d + c] = ab[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    atomicAdd(dgamma + c, rg[c] + rg[d + c] + rg[2 * d + c] + rg[3 * d + c]);
+    atomicAdd(dbeta + c, rb[c] + rb[d + c] + rb[2 * d + c] + rb[3 * d + c]);
+  }
+}
+
+extern "C" int nast_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                      float* rstd, int rows_out, int d, float eps, int grp, int grp_stride,
+                                      int grp_off, void* stream) {
+  NAST_REQUIRE(d >= 1 && d <= 64 * LN_MAX_PER_LANE, "nast_layernorm_fwd_f32: d=%d unsupported (max %d)", d, 64 * LN_MAX_PER_LANE);
+  NAST_REQUIRE(rows_out >= 0, "nast_layernorm_fwd_f32: rows_out < 0");
+  if (rows_out == 0) return NAST_OK;
+  NAST_REQUIRE(x && gamma && beta && y && mean && rstd, "nast_layernorm_fwd_f32: NULL pointer");
+  hipLaunchKernelGGL(nast_ln_fwd_kernel, dim3((rows_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                     mean, rstd, rows_out, d, eps, grp, grp_stride, grp_off);
+  NAST_CHECK_LAUNCH("nast_layernorm_fwd_f32");
+  return NAST_OK;
+}
+
+extern "C" int nast_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                      const float* rstd, float* dx, float* dgamma, float* dbeta, const float* dx_add,
+                                      int rows_out, int rows_in, int d, int grp, int grp_stride, int grp_off, void* stream) {
+  NAST_REQUIRE(dx_add == nullptr || grp == 0, "nast_layernorm_bwd_f32: dx_add needs the identity row map");
+  NAST_REQUIRE(d >= 1 && d <= 64 * LN_MAX_PER_LANE, "nast_layernorm_bwd_f32: d=%d unsupported", d);
+  NAST_REQUIRE(rows_out >= 0 && rows_in >= rows_out, "nast_layernorm_bwd_f32: bad row counts %d/%d", rows_out, rows_in);
+  if (rows_in == 0) return NAST_OK;
+  NAST_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "nast_layernorm_bwd_f32: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (grp > 0) {
+    if (hipMemsetAsync(dx, 0, (size_t)rows_in * d * sizeof(float), s) != hipSuccess) {
+      nast_set_error("nast_layernorm_bwd_f32: memset failed");
+      return NAST_ELAUNCH;
+    }
+  }
+  if (rows_out == 0) return NAST_OK;
+  int blocks = (rows_out + 3) / 4;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(nast_ln_bwd_kernel, dim3(blocks), dim3(256), 2 * 4 * d * sizeof(float), s, dy, x, gamma, mean, rstd,
+                     dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+  NAST_CHECK_LAUNCH("nast_layernorm_bwd_f32");
+  return NAST_OK;
+}

@@ -1,0 +1,322 @@
+// Row kernels over the vocabulary axis: log-softmax (generator), Gumbel-softmax sampling, their
+// backward passes, and get_lengths.  HBM-bound: one 256-thread workgroup per row, 16-B accesses when the
+// row is 16-B aligned; the row is read from HBM once (later passes hit L2: a 9600-float row is 38 KB).
+#include "common.h"
+
+struct RowSpan {
+  int nvec;   // number of float4 chunks handled vectorised
+  int tail0;  // first scalar column
+};
+
+__device__ __forceinline__ RowSpan row_span(int V, bool aligned) {
+  RowSpan s;
+  s.nvec = aligned ? V / 4 : 0;
+  s.tail0 = s.nvec * 4;
+  return s;
+}
+
+__device__ __forceinline__ bool ptr16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// log_softmax
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nast_log_softmax_fwd_kernel(const float* __restrict__ x, nast_rows xr,
+                                                                   float* __restrict__ y, nast_rows yr, int V, float it) {
+  __shared__ float red[4];
+  const int64_t r = blockIdx.x;
+  const float* xp = x + row_offset(r, xr);
+  float* yp = y + row_offset(r, yr);
+  const RowSpan sp = row_span(V, ptr16(xp) && ptr16(yp));
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    const float4 t = reinterpret_cast<const float4*>(xp)[c];
+    m = fmaxf(fmaxf(m, fmaxf(t.x, t.y) * it), fmaxf(t.z, t.w) * it);
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) m = fmaxf(m, xp[c] * it);
+  // NB: max(x)*it == max(x*it) only for it > 0 (checked on the host)
+  m = block_max<256>(m, red);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    const float4 t = reinterpret_cast<const float4*>(xp)[c];
+    s += __expf(t.x * it - m) + __expf(t.y * it - m) + __expf(t.z * it - m) + __expf(t.w * it - m);
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) s += __expf(xp[c] * it - m);
+  s = block_sum<256>(s, red);
+  const float lz = m + __logf(s);
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    float4 t = reinterpret_cast<const float4*>(xp)[c];
+    t.x = t.x * it - lz; t.y = t.y * it - lz; t.z = t.z * it - lz; t.w = t.w * it - lz;
+    reinterpret_cast<float4*>(yp)[c] = t;
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) yp[c] = xp[c] * it - lz;
+}
+
+__global__ __launch_bounds__(256) void nast_log_softmax_bwd_kernel(const float* __restrict__ gy, nast_rows gyr,
+                                                                   const float* __restrict__ y, nast_rows yr,
+                                                                   float* __restrict__ gx, nast_rows gxr, int V, float it) {
+  __shared__ float red[4];
+  const int64_t r = blockIdx.x;
+  const float* gp = gy + row_offset(r, gyr);
+  const float* yp = y + row_offset(r, yr);
+  float* op = gx + row_offset(r, gxr);
+  const RowSpan sp = row_span(V, ptr16(gp) && ptr16(yp) && ptr16(op));
+  float s = 0.f;
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    const float4 t = reinterpret_cast<const float4*>(gp)[c];
+    s += (t.x + t.y) + (t.z + t.w);
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) s += gp[c];
+  s = block_sum<256>(s, red);
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    const float4 g = reinterpret_cast<const float4*>(gp)[c];
+    const float4 l = reinterpret_cast<const float4*>(yp)[c];
+    float4 o;
+    o.x = (g.x - __expf(l.x) * s) * it; o.y = (g.y - __expf(l.y) * s) * it;
+    o.z = (g.z - __expf(l.z) * s) * it; o.w = (g.w - __expf(l.w) * s) * it;
+    reinterpret_cast<float4*>(op)[c] = o;
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) op[c] = (gp[c] - __expf(yp[c]) * s) * it;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gumbel softmax
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Exp(1) draw from 32 random bits: U in (0,1], E = -log(U)
+__device__ __forceinline__ float exp1_from_bits(uint32_t b) {
+  const float u = ((float)(b >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  return -__logf(u);
+}
+
+// gumbel noise of utils/gumbel.py:36  g = min(-log(E), 1e10)
+__device__ __forceinline__ float gumbel_of(float E) { return fminf(-logf(E), 1e10f); }
+
+struct Best {
+  float v;
+  int i;
+};
+__device__ __forceinline__ void best_upd(Best& b, float v, int i) {
+  if (v > b.v || (v == b.v && i < b.i)) {
+    b.v = v;
+    b.i = i;
+  }
+}
+
+__global__ __launch_bounds__(256) void nast_gumbel_softmax_fwd_kernel(const float* __restrict__ logits, nast_rows lr,
+                                                                      const float* __restrict__ E, nast_rows er,
+                                                                      const int64_t* __restrict__ mask,
+                                                                      float* __restrict__ y, nast_rows yr,
+                                                                      int64_t* __restrict__ idx, int V, float it,
+                                                                      uint64_t seed, uint64_t offset, int noise_off) {
+  __shared__ float red[4];
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const int64_t r = blockIdx.x;
+  const float* lp = logits + row_offset(r, lr);
+  const float* ep = E ? E + row_offset(r, er) : nullptr;
+  const int64_t* mp = mask ? mask + r * (int64_t)V : nullptr;
+  float* yp = y + row_offset(r, yr);
+  const RowSpan sp = row_span(V, ptr16(lp) && ptr16(yp) && (!ep || ptr16(ep)));
+  Best best{-INFINITY, 0x7fffffff};
+  // pass A: z = (logit + g) * it -> y, running max / argmax
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    const float4 l = reinterpret_cast<const float4*>(lp)[c];
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!noise_off) {
+      if (ep) {
+        const float4 e = reinterpret_cast<const float4*>(ep)[c];
+        g[0] = gumbel_of(e.x); g[1] = gumbel_of(e.y); g[2] = gumbel_of(e.z); g[3] = gumbel_of(e.w);
+      } else {
+        uint32_t rb[4];
+        const uint64_t ctr = (uint64_t)r * (uint64_t)((V + 3) / 4) + c;
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                      (uint32_t)(seed >> 32), rb);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = gumbel_of(exp1_from_bits(rb[u]));
+      }
+    }
+    float z[4] = {(l.x + g[0]) * it, (l.y + g[1]) * it, (l.z + g[2]) * it, (l.w + g[3]) * it};
+    if (mp) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (mp[4 * c + u] == 0) z[u] = -1e9f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) best_upd(best, z[u], 4 * c + u);
+    reinterpret_cast<float4*>(yp)[c] = make_float4(z[0], z[1], z[2], z[3]);
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) {
+    float g = 0.f;
+    if (!noise_off) {
+      if (ep) {
+        g = gumbel_of(ep[c]);
+      } else {
+        uint32_t rb[4];
+        const uint64_t ctr = (uint64_t)r * (uint64_t)((V + 3) / 4) + (c >> 2);
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                      (uint32_t)(seed >> 32), rb);
+        g = gumbel_of(exp1_from_bits(rb[c & 3]));
+      }
+    }
+    float z = (lp[c] + g) * it;
+    if (mp && mp[c] == 0) z = -1e9f;
+    best_upd(best, z, c);
+    yp[c] = z;
+  }
+  // block argmax (first index wins ties, as torch.max(dim))
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best.v, o, 64);
+    const int oi = __shfl_xor(best.i, o, 64);
+    best_upd(best, ov, oi);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    bv[w] = best.v;
+    bi[w] = best.i;
+  }
+  __syncthreads();
+  Best all{bv[0], bi[0]};
+#pragma unroll
+  for (int i = 1; i < 4; ++i) best_upd(all, bv[i], bi[i]);
+  const float m = all.v;
+  if (idx && threadIdx.x == 0) idx[r] = all.i;
+  // pass B: e = exp(z - m) -> y, sum   (each thread re-reads only what it wrote itself)
+  float s = 0.f;
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    float4 t = reinterpret_cast<float4*>(yp)[c];
+    t.x = __expf(t.x - m); t.y = __expf(t.y - m); t.z = __expf(t.z - m); t.w = __expf(t.w - m);
+    s += (t.x + t.y) + (t.z + t.w);
+    reinterpret_cast<float4*>(yp)[c] = t;
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) {
+    const float e = __expf(yp[c] - m);
+    s += e;
+    yp[c] = e;
+  }
+  s = block_sum<256>(s, red);
+  const float inv = 1.f / s;
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    float4 t = reinterpret_cast<float4*>(yp)[c];
+    t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
+    reinterpret_cast<float4*>(yp)[c] = t;
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) yp[c] *= inv;
+}
+
+__global__ __launch_bounds__(256) void nast_softmax_bwd_kernel(const float* __restrict__ gy, nast_rows gyr,
+                                                               const float* __restrict__ y, nast_rows yr,
+                                                               float* __restrict__ gx, nast_rows gxr, int V, float it) {
+  __shared__ float red[4];
+  const int64_t r = blockIdx.x;
+  const float* gp = gy + row_offset(r, gyr);
+  const float* yp = y + row_offset(r, yr);
+  float* op = gx + row_offset(r, gxr);
+  const RowSpan sp = row_span(V, ptr16(gp) && ptr16(yp) && ptr16(op));
+  float s = 0.f;
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    const float4 g = reinterpret_cast<const float4*>(gp)[c];
+    const float4 p = reinterpret_cast<const float4*>(yp)[c];
+    s += (g.x * p.x + g.y * p.y) + (g.z * p.z + g.w * p.w);
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) s += gp[c] * yp[c];
+  s = block_sum<256>(s, red);
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    const float4 g = reinterpret_cast<const float4*>(gp)[c];
+    const float4 p = reinterpret_cast<const float4*>(yp)[c];
+    float4 o;
+    o.x = p.x * (g.x - s) * it; o.y = p.y * (g.y - s) * it; o.z = p.z * (g.z - s) * it; o.w = p.w * (g.w - s) * it;
+    reinterpret_cast<float4*>(op)[c] = o;
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) op[c] = yp[c] * (gp[c] - s) * it;
+}
+
+__global__ void nast_first_eos_kernel(const int64_t* __restrict__ tok, int64_t* __restrict__ len, int B, int L, int64_t eos) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = L;
+  for (int i = 0; i < L; ++i)
+    if (tok[(int64_t)b * L + i] == eos) {
+      n = i;
+      break;
+    }
+  len[b] = (n + 1 < L) ? n + 1 : L;
+}
+
+// ---------------------------------------------------------------------------------------------
+static bool rows_ok(nast_rows a, int V) {
+  // vector path needs every row start 16-B aligned relative to the base; the kernels test the actual
+  // pointer per row, so nothing to enforce here beyond sanity
+  return a.ld >= V || a.ld == 0;
+}
+
+extern "C" int nast_log_softmax_fwd_f32(const float* x, nast_rows xr, float* y, nast_rows yr, int rows, int V, float inv_temp,
+                                        void* stream) {
+  NAST_REQUIRE(rows >= 0 && V >= 1, "nast_log_softmax_fwd_f32: bad sizes rows=%d V=%d", rows, V);
+  NAST_REQUIRE(inv_temp > 0.f, "nast_log_softmax_fwd_f32: temperature must be > 0");
+  if (rows == 0) return NAST_OK;
+  NAST_REQUIRE(x && y && rows_ok(xr, V) && rows_ok(yr, V), "nast_log_softmax_fwd_f32: bad pointer/stride");
+  hipLaunchKernelGGL(nast_log_softmax_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, xr, y, yr, V, inv_temp);
+  NAST_CHECK_LAUNCH("nast_log_softmax_fwd_f32");
+  return NAST_OK;
+}
+
+extern "C" int nast_log_softmax_bwd_f32(const float* gy, nast_rows gyr, const float* y, nast_rows yr, float* gx, nast_rows gxr,
+                                        int rows, int V, float inv_temp, void* stream) {
+  NAST_REQUIRE(rows >= 0 && V >= 1, "nast_log_softmax_bwd_f32: bad sizes");
+  if (rows == 0) return NAST_OK;
+  NAST_REQUIRE(gy && y && gx, "nast_log_softmax_bwd_f32: NULL pointer");
+  hipLaunchKernelGGL(nast_log_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, gy, gyr, y, yr, gx, gxr, V,
+                     inv_temp);
+  NAST_CHECK_LAUNCH("nast_log_softmax_bwd_f32");
+  return NAST_OK;
+}
+
+extern "C" int nast_gumbel_softmax_fwd_f32(const float* logits, nast_rows lr, const float* E, nast_rows er, const int64_t* mask,
+                                           float* y, nast_rows yr, int64_t* idx, int rows, int V, float inv_tau, uint64_t seed,
+                                           uint64_t offset, int noise_off, void* stream) {
+  NAST_REQUIRE(rows >= 0 && V >= 1, "nast_gumbel_softmax_fwd_f32: bad sizes");
+  NAST_REQUIRE(inv_tau > 0.f, "nast_gumbel_softmax_fwd_f32: tau must be > 0");
+  if (rows == 0) return NAST_OK;
+  NAST_REQUIRE(logits && y, "nast_gumbel_softmax_fwd_f32: NULL pointer");
+  NAST_REQUIRE(logits != y, "nast_gumbel_softmax_fwd_f32: in-place not supported");
+  hipLaunchKernelGGL(nast_gumbel_softmax_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, lr, E, er, mask, y,
+                     yr, idx, V, inv_tau, seed, offset, noise_off);
+  NAST_CHECK_LAUNCH("nast_gumbel_softmax_fwd_f32");
+  return NAST_OK;
+}
+
+extern "C" int nast_softmax_bwd_f32(const float* gy, nast_rows gyr, const float* y, nast_rows yr, float* gx, nast_rows gxr,
+                                    int rows, int V, float inv_tau, void* stream) {
+  NAST_REQUIRE(rows >= 0 && V >= 1, "nast_softmax_bwd_f32: bad sizes");
+  if (rows == 0) return NAST_OK;
+  NAST_REQUIRE(gy && y && gx, "nast_softmax_bwd_f32: NULL pointer");
+  hipLaunchKernelGGL(nast_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, gy, gyr, y, yr, gx, gxr, V, inv_tau);
+  NAST_CHECK_LAUNCH("nast_softmax_bwd_f32");
+  return NAST_OK;
+}
+
+extern "C" int nast_first_eos_length_i64(const int64_t* tokens, int64_t* lengths, int B, int L, int64_t eos, void* stream) {
+  NAST_REQUIRE(B >= 0 && L >= 1, "nast_first_eos_length_i64: bad sizes");
+  if (B == 0) return NAST_OK;
+  NAST_REQUIRE(tokens && lengths, "nast_first_eos_length_i64: NULL pointer");
+  hipLaunchKernelGGL(nast_first_eos_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tokens, lengths, B, L, eos);
+  NAST_CHECK_LAUNCH("nast_first_eos_length_i64");
+  return NAST_OK;
+}

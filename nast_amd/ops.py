@@ -1,0 +1,675 @@
+"""torch.autograd.Function wrappers over libnast_hip.so.
+
+PyTorch is used here for device memory (torch.empty), the current HIP stream and autograd bookkeeping only;
+every numeric operation is a hand-written gfx950 kernel reached through the C-ABI (nast_amd/_lib.py).
+There is no CPU / eager fallback: a non-CUDA tensor raises.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, Rows, GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, call
+
+F32 = torch.float32
+
+
+# ------------------------------------------------------------------------------------------------
+# plumbing
+# ------------------------------------------------------------------------------------------------
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.NastHipError("nast_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != F32:
+            raise _lib.NastHipError(f"fp32 tensor expected, got {t.dtype}")
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _flat_rows(n_rows, ld):
+    return Rows(ld, 0, 0)
+
+
+def desc(A, B, Cm, M, N, K, lda, ldb, ldc, transA, transB, bias=None, residual=None, relu_src=None, colsum=None,
+         flags=0, alpha=1.0):
+    """Build one nast_gemm_desc. A / B may be a tensor or a list of up to 3 tensors (summed products)."""
+    d = GemmDesc()
+    As = A if isinstance(A, (list, tuple)) else (A,)
+    Bs = B if isinstance(B, (list, tuple)) else (B,)
+    for i, (a, b) in enumerate(zip(As, Bs)):
+        d.A[i] = a.data_ptr()
+        d.B[i] = b.data_ptr()
+    d.nsrc = len(As)
+    d.C = Cm.data_ptr()
+    d.bias = _p(bias)
+    d.residual = _p(residual)
+    d.relu_src = _p(relu_src)
+    d.colsum = _p(colsum)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.transA, d.transB = transA, transB
+    d.flags = flags
+    d.alpha = alpha
+    return d
+
+
+def gemm(descs):
+    """Launch up to 8 GEMMs as one grouped kernel."""
+    for i in range(0, len(descs), _lib.GEMM_MAX_GROUP):
+        chunk = descs[i:i + _lib.GEMM_MAX_GROUP]
+        arr = (GemmDesc * len(chunk))(*chunk)
+        call("nast_gemm_f32", arr, len(chunk), _stream())
+
+
+# descriptor shorthands for the three layouts of a Linear layer: y[M,N] = x[M,K] @ W[N,K]^T
+def d_fwd(x2, W, y2, bias=None, residual=None, relu=False):
+    M, K = x2.shape
+    N = W.shape[0]
+    return desc(x2, W, y2, M, N, K, K, K, N, 0, 1, bias=bias, residual=residual, flags=GEMM_RELU if relu else 0)
+
+
+def d_dgrad(dy2_list, W_list, dx2, relu_src=None):
+    """dx[M,K] = sum_i dy_i[M,N] @ W_i[N,K]"""
+    dy0, W0 = dy2_list[0], W_list[0]
+    M, N = dy0.shape
+    K = W0.shape[1]
+    return desc(list(dy2_list), list(W_list), dx2, M, K, N, N, K, K, 0, 0, relu_src=relu_src)
+
+
+def d_wgrad(dy2, x2, dW, db=None):
+    """dW[N,K] += dy[M,N]^T @ x[M,K]  (atomic, split-K), db[N] += colsum(dy)"""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    return desc(dy2, x2, dW, N, K, M, N, K, K, 1, 0, colsum=db, flags=GEMM_ATOMIC)
+
+
+def zeros_like_many(tensors):
+    """One zero-filled flat buffer carved into views shaped like `tensors` (a single fill kernel)."""
+    sizes = [t.numel() for t in tensors]
+    # keep every view 16-B aligned
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 3) // 4 * 4
+    flat = torch.zeros(tot, device=tensors[0].device, dtype=F32)
+    return [flat[o:o + n].view(t.shape) for o, n, t in zip(offs, sizes, tensors)]
+
+
+# ------------------------------------------------------------------------------------------------
+# raw kernel calls (no autograd)
+# ------------------------------------------------------------------------------------------------
+def ln_fwd(x2, gamma, beta, rows_out=None, grp=0, grp_stride=0, grp_off=0, eps=1e-6):
+    rows_in, d = x2.shape
+    rows_out = rows_in if rows_out is None else rows_out
+    y = torch.empty(rows_out, d, device=x2.device, dtype=F32)
+    mean = torch.empty(rows_out, device=x2.device, dtype=F32)
+    rstd = torch.empty(rows_out, device=x2.device, dtype=F32)
+    call("nast_layernorm_fwd_f32", _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows_out, d, eps,
+         grp, grp_stride, grp_off, _stream())
+    return y, mean, rstd
+
+
+def ln_bwd(dy2, x2, gamma, mean, rstd, dgamma, dbeta, dx_add=None, grp=0, grp_stride=0, grp_off=0):
+    rows_in, d = x2.shape
+    dx = torch.empty_like(x2)
+    call("nast_layernorm_bwd_f32", _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
+         _p(dx_add), dy2.shape[0], rows_in, d, grp, grp_stride, grp_off, _stream())
+    return dx
+
+
+def _mask_args(mask, B, nq, nk):
+    """bool mask broadcastable to [B, h, nq, nk] with size-1 head dim -> (ptr holder, batch stride, query stride)."""
+    if mask is None:
+        return None, 0, 0
+    if mask.dtype != torch.bool and mask.dtype != torch.uint8:
+        mask = mask != 0
+    if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[3] != nk or mask.shape[0] not in (1, B) or mask.shape[2] not in (1, nq):
+        raise _lib.NastHipError(f"unsupported attention mask shape {tuple(mask.shape)} for B={B} nq={nq} nk={nk}")
+    if mask.stride(3) != 1 and nk > 1:
+        mask = mask.contiguous()
+    bs = mask.stride(0) if mask.shape[0] > 1 else 0
+    qs = mask.stride(2) if mask.shape[2] > 1 else 0
+    return mask, bs, qs
+
+
+def mha_fwd(q, k, v, mask, h):
+    """q [B,nq,D], k/v [B,nk,D] contiguous -> out [B,nq,D], lse [B,h,nq]"""
+    B, nq, D = q.shape
+    nk = k.shape[1]
+    dk = D // h
+    out = torch.empty_like(q)
+    lse = torch.empty(B, h, nq, device=q.device, dtype=F32)
+    m, bs, qs = _mask_args(mask, B, nq, nk)
+    call("nast_mha_fwd_f32", _p(q), _p(k), _p(v), _p(m), _p(out), _p(lse), B, h, nq, nk, dk, D, D, D, D, bs, qs,
+         1.0 / math.sqrt(dk), _stream())
+    return out, lse
+
+
+def mha_bwd(q, k, v, mask, h, out, dout, lse):
+    B, nq, D = q.shape
+    nk = k.shape[1]
+    dk = D // h
+    dq, dk_, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    m, bs, qs = _mask_args(mask, B, nq, nk)
+    call("nast_mha_bwd_f32", _p(q), _p(k), _p(v), _p(m), _p(out), _p(dout), _p(lse), _p(dq), _p(dk_), _p(dv),
+         B, h, nq, nk, dk, D, D, D, D, bs, qs, 1.0 / math.sqrt(dk), _stream())
+    return dq, dk_, dv
+
+
+def rows_of(t):
+    """nast_rows for a tensor whose last dim is the (contiguous) vocabulary axis: [R,V] or [B,L,V] views."""
+    if t.stride(-1) != 1:
+        raise _lib.NastHipError("vocabulary axis must be contiguous")
+    if t.dim() == 2:
+        return Rows(t.stride(0), 0, 0), t.shape[0]
+    if t.dim() == 3:
+        return Rows(t.stride(1), t.shape[1], t.stride(0)), t.shape[0] * t.shape[1]
+    raise _lib.NastHipError(f"row kernels take 2-D or 3-D tensors, got {t.dim()}-D")
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions: fine-grained (public module API) ...
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b  [+ residual] [ReLU]   (nn.Linear, transformer.py:280-281, :309-312, :390-392)"""
+
+    @staticmethod
+    def forward(ctx, x, W, b, residual, relu):
+        _chk(x, W, b, residual)
+        x2 = _c(x).view(-1, x.shape[-1])
+        W = _c(W)
+        y2 = torch.empty(x2.shape[0], W.shape[0], device=x.device, dtype=F32)
+        r2 = _c(residual).view(-1, W.shape[0]) if residual is not None else None
+        gemm([d_fwd(x2, W, y2, bias=b, residual=r2, relu=relu)])
+        ctx.save_for_backward(x2, W, y2 if relu else None)
+        ctx.has_b, ctx.has_res, ctx.relu, ctx.xshape = b is not None, residual is not None, relu, x.shape
+        return y2.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y2 = ctx.saved_tensors
+        dy2 = _c(dy).view(-1, W.shape[0])
+        if ctx.relu:
+            dy2 = dy2 * (y2 > 0)   # only on the fine-grained path; the fused FFN masks inside the dgrad epilogue
+        dW, db = zeros_like_many([W, W.new_empty(W.shape[0])])
+        descs = [d_wgrad(dy2, x2, dW, db if ctx.has_b else None)]
+        dx2 = None
+        if ctx.needs_input_grad[0]:
+            dx2 = torch.empty_like(x2)
+            descs.append(d_dgrad([dy2], [W], dx2))
+        gemm(descs)
+        return (dx2.view(ctx.xshape) if dx2 is not None else None, dW, db if ctx.has_b else None,
+                dy if ctx.has_res else None, None)
+
+
+def linear(x, W, b=None, residual=None, relu=False):
+    return LinearFn.apply(x, W, b, residual, relu)
+
+
+class MatmulNNFn(torch.autograd.Function):
+    """y[M,N] = x[M,K] @ E[K,N]   (soft tokens x embedding table, transformer.py:229, :403)"""
+
+    @staticmethod
+    def forward(ctx, x, E):
+        _chk(x, E)
+        x2 = _c(x).view(-1, x.shape[-1])
+        E = _c(E)
+        M, K = x2.shape
+        N = E.shape[1]
+        y2 = torch.empty(M, N, device=x.device, dtype=F32)
+        gemm([desc(x2, E, y2, M, N, K, K, N, N, 0, 0)])
+        ctx.save_for_backward(x2, E)
+        ctx.xshape = x.shape
+        return y2.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, E = ctx.saved_tensors
+        M, K = x2.shape
+        N = E.shape[1]
+        dy2 = _c(dy).view(M, N)
+        descs, dx2, dE = [], None, None
+        if ctx.needs_input_grad[0]:
+            dx2 = torch.empty_like(x2)                       # dX = dY E^T
+            descs.append(desc(dy2, E, dx2, M, K, N, N, N, K, 0, 1))
+        if ctx.needs_input_grad[1]:
+            dE = torch.zeros_like(E)                         # dE = X^T dY
+            descs.append(desc(x2, dy2, dE, K, N, M, K, N, N, 1, 0, flags=GEMM_ATOMIC))
+        gemm(descs)
+        return (dx2.view(ctx.xshape) if dx2 is not None else None), dE
+
+
+def matmul_nn(x, E):
+    return MatmulNNFn.apply(x, E)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm(d, eps=1e-6) (transformer.py:348-350) with an optional output-row map."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, grp, grp_stride, grp_off, rows_out):
+        _chk(x, gamma, beta)
+        x2 = _c(x).view(-1, x.shape[-1])
+        y, mean, rstd = ln_fwd(x2, gamma, beta, rows_out if grp else None, grp, grp_stride, grp_off)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.map = (grp, grp_stride, grp_off)
+        ctx.xshape = x.shape
+        return y if grp else y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        dg, db = zeros_like_many([gamma, gamma])
+        dy2 = _c(dy).view(-1, x2.shape[1])
+        dx = ln_bwd(dy2, x2, gamma, mean, rstd, dg, db, None, *ctx.map)
+        return dx.view(ctx.xshape), dg, db, None, None, None, None
+
+
+def layer_norm(x, gamma, beta):
+    return LayerNormFn.apply(x, gamma, beta, 0, 0, 0, 0)
+
+
+def layer_norm_rows(x, gamma, beta, grp, grp_stride, grp_off, rows_out):
+    """LayerNorm of selected rows only: output row r <- input row (r//grp)*grp_stride + grp_off + r%grp."""
+    return LayerNormFn.apply(x, gamma, beta, grp, grp_stride, grp_off, rows_out)
+
+
+class AttentionFn(torch.autograd.Function):
+    """scaled_attention on [B,n,h*dk] projections (transformer.py:296-303 + the transposes of :287-292)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, h):
+        _chk(q, k, v)
+        q, k, v = _c(q), _c(k), _c(v)
+        out, lse = mha_fwd(q, k, v, mask, h)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.mask, ctx.h = mask, h
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk_, dv = mha_bwd(q, k, v, ctx.mask, ctx.h, out, _c(dout), lse)
+        return dq, dk_, dv, None, None
+
+
+def attention(q, k, v, mask, h):
+    return AttentionFn.apply(q, k, v, mask, h)
+
+
+# ------------------------------------------------------------------------------------------------
+# ... and fused sublayers (what the Encoder/Decoder layers actually run)
+# ------------------------------------------------------------------------------------------------
+class AttnSublayerFn(torch.autograd.Function):
+    """x + fc(MHA(LN(x) Wq, kv Wk, kv Wv))  -- SublayerConnection around MultiHeadAttention
+    (transformer.py:324-326 + :284-294).  kv_src None = self-attention on LN(x); otherwise cross-attention
+    on `kv_src` (the encoder memory, not normalised, transformer.py:256)."""
+
+    @staticmethod
+    def forward(ctx, x, kv_src, mask, h, ln_w, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo):
+        _chk(x, kv_src, ln_w, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        B, nq, d = x.shape
+        x2 = _c(x).view(-1, d)
+        z, mean, rstd = ln_fwd(x2, ln_w, ln_b)
+        self_attn = kv_src is None
+        kv2 = z if self_attn else _c(kv_src).view(-1, d)
+        nk = nq if self_attn else kv_src.shape[1]
+        q = torch.empty(B * nq, d, device=x.device, dtype=F32)
+        k = torch.empty(B * nk, d, device=x.device, dtype=F32)
+        v = torch.empty(B * nk, d, device=x.device, dtype=F32)
+        gemm([d_fwd(z, Wq, q, bias=bq), d_fwd(kv2, Wk, k, bias=bk), d_fwd(kv2, Wv, v, bias=bv)])
+        a, lse = mha_fwd(q.view(B, nq, d), k.view(B, nk, d), v.view(B, nk, d), mask, h)
+        y = torch.empty_like(x2)
+        gemm([d_fwd(a.view(-1, d), Wo, y, bias=bo, residual=x2)])
+        ctx.save_for_backward(x2, z, mean, rstd, kv2 if not self_attn else None, q, k, v, a, lse,
+                              ln_w, Wq, Wk, Wv, Wo)
+        ctx.mask, ctx.h, ctx.self_attn, ctx.shape, ctx.nk = mask, h, self_attn, (B, nq, d), nk
+        return y.view(B, nq, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, z, mean, rstd, kv2, q, k, v, a, lse, ln_w, Wq, Wk, Wv, Wo = ctx.saved_tensors
+        B, nq, d = ctx.shape
+        nk = ctx.nk
+        if kv2 is None:
+            kv2 = z
+        dy2 = _c(dy).view(-1, d)
+        dlnw, dlnb, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo = zeros_like_many(
+            [ln_w, ln_w, Wq, ln_w, Wk, ln_w, Wv, ln_w, Wo, ln_w])
+        da = torch.empty_like(a).view(-1, d)
+        gemm([d_dgrad([dy2], [Wo], da), d_wgrad(dy2, a.view(-1, d), dWo, dbo)])
+        dq, dk_, dv = mha_bwd(q.view(B, nq, d), k.view(B, nk, d), v.view(B, nk, d), ctx.mask, ctx.h, a, da.view(B, nq, d), lse)
+        dq2, dk2, dv2 = dq.view(-1, d), dk_.view(-1, d), dv.view(-1, d)
+        dz = torch.empty_like(z)
+        descs = [d_wgrad(dq2, z, dWq, dbq), d_wgrad(dk2, kv2, dWk, dbk), d_wgrad(dv2, kv2, dWv, dbv)]
+        dkv = None
+        if ctx.self_attn:
+            descs.append(d_dgrad([dq2, dk2, dv2], [Wq, Wk, Wv], dz))
+        else:
+            descs.append(d_dgrad([dq2], [Wq], dz))
+            if ctx.needs_input_grad[1]:
+                dkv = torch.empty_like(kv2)
+                descs.append(d_dgrad([dk2, dv2], [Wk, Wv], dkv))
+        gemm(descs)
+        dx = ln_bwd(dz, x2, ln_w, mean, rstd, dlnw, dlnb, dx_add=dy2)
+        return (dx.view(B, nq, d), dkv.view(B, nk, d) if dkv is not None else None, None, None,
+                dlnw, dlnb, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo)
+
+
+class FFNSublayerFn(torch.autograd.Function):
+    """x + W2 relu(W1 LN(x) + b1) + b2   (transformer.py:324-326 around :305-316)"""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, W1, b1, W2, b2):
+        _chk(x, ln_w, ln_b, W1, b1, W2, b2)
+        shape = x.shape
+        d = shape[-1]
+        x2 = _c(x).view(-1, d)
+        z, mean, rstd = ln_fwd(x2, ln_w, ln_b)
+        hmid = torch.empty(x2.shape[0], W1.shape[0], device=x.device, dtype=F32)
+        gemm([d_fwd(z, W1, hmid, bias=b1, relu=True)])
+        y = torch.empty_like(x2)
+        gemm([d_fwd(hmid, W2, y, bias=b2, residual=x2)])
+        ctx.save_for_backward(x2, z, mean, rstd, hmid, ln_w, W1, W2)
+        ctx.shape = shape
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, z, mean, rstd, hmid, ln_w, W1, W2 = ctx.saved_tensors
+        d = x2.shape[1]
+        dy2 = _c(dy).view(-1, d)
+        dlnw, dlnb, dW1, db1, dW2, db2 = zeros_like_many([ln_w, ln_w, W1, W1.new_empty(W1.shape[0]), W2, ln_w])
+        dh = torch.empty_like(hmid)
+        gemm([d_dgrad([dy2], [W2], dh, relu_src=hmid), d_wgrad(dy2, hmid, dW2, db2)])
+        dz = torch.empty_like(z)
+        gemm([d_dgrad([dh], [W1], dz), d_wgrad(dh, z, dW1, db1)])
+        dx = ln_bwd(dz, x2, ln_w, mean, rstd, dlnw, dlnb, dx_add=dy2)
+        return dx.view(ctx.shape), dlnw, dlnb, dW1, db1, dW2, db2
+
+
+def attn_sublayer(x, kv_src, mask, h, ln, mha):
+    p = mha.head_projs
+    return AttnSublayerFn.apply(x, kv_src, mask, h, ln.weight, ln.bias, p[0].weight, p[0].bias, p[1].weight, p[1].bias,
+                                p[2].weight, p[2].bias, mha.fc.weight, mha.fc.bias)
+
+
+def ffn_sublayer(x, ln, ffn):
+    return FFNSublayerFn.apply(x, ln.weight, ln.bias, ffn.mlp[0].weight, ffn.mlp[0].bias, ffn.mlp[3].weight, ffn.mlp[3].bias)
+
+
+# ------------------------------------------------------------------------------------------------
+# generator / softmax family
+# ------------------------------------------------------------------------------------------------
+class GeneratorFn(torch.autograd.Function):
+    """log_softmax((x W^T + b) / temperature)   (Generator.forward, transformer.py:213-214)"""
+
+    @staticmethod
+    def forward(ctx, x, W, b, temperature):
+        _chk(x, W, b)
+        x2 = _c(x).view(-1, x.shape[-1])
+        V = W.shape[0]
+        y = torch.empty(x2.shape[0], V, device=x.device, dtype=F32)
+        gemm([d_fwd(x2, W, y, bias=b)])
+        r = Rows(V, 0, 0)
+        call("nast_log_softmax_fwd_f32", _p(y), r, _p(y), r, y.shape[0], V, 1.0 / temperature, _stream())
+        ctx.save_for_backward(x2, W, y)
+        ctx.it, ctx.xshape = 1.0 / temperature, x.shape
+        return y.view(*x.shape[:-1], V)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, W, y = ctx.saved_tensors
+        V = W.shape[0]
+        gy2 = _c(gy).view(-1, V)
+        gl = torch.empty_like(y)
+        r = Rows(V, 0, 0)
+        call("nast_log_softmax_bwd_f32", _p(gy2), r, _p(y), r, _p(gl), r, y.shape[0], V, ctx.it, _stream())
+        dW, db = zeros_like_many([W, W.new_empty(V)])
+        dx = torch.empty_like(x2)
+        gemm([d_dgrad([gl], [W], dx), d_wgrad(gl, x2, dW, db)])
+        return dx.view(ctx.xshape), dW, db, None
+
+
+def generator(x, W, b, temperature):
+    return GeneratorFn.apply(x, W, b, float(temperature))
+
+
+class LogSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        x2 = _c(x).view(-1, x.shape[-1])
+        V = x2.shape[1]
+        y = torch.empty_like(x2)
+        r = Rows(V, 0, 0)
+        call("nast_log_softmax_fwd_f32", _p(x2), r, _p(y), r, y.shape[0], V, 1.0, _stream())
+        ctx.save_for_backward(y)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        V = y.shape[1]
+        gy2 = _c(gy).view(-1, V)
+        gx = torch.empty_like(y)
+        r = Rows(V, 0, 0)
+        call("nast_log_softmax_bwd_f32", _p(gy2), r, _p(y), r, _p(gx), r, y.shape[0], V, 1.0, _stream())
+        return gx.view(gy.shape)
+
+
+def log_softmax(x):
+    return LogSoftmaxFn.apply(x)
+
+
+class GumbelSoftmaxFn(torch.autograd.Function):
+    """y_soft = softmax((logits + g) / tau), g = min(-log(E), 1e10)   (utils/gumbel.py:28-30, :36-38).
+    E = injected Exp(1) draw (parity) or None (in-kernel Philox keyed by torch's CUDA generator)."""
+
+    @staticmethod
+    def forward(ctx, logits, E, mask, tau, noise_off):
+        _chk(logits, E)
+        V = logits.shape[-1]
+        lr, rows = rows_of(logits)
+        y = torch.empty(logits.shape, device=logits.device, dtype=F32)
+        yr, _ = rows_of(y)
+        idx = torch.empty(logits.shape[:-1], device=logits.device, dtype=torch.int64)
+        seed = offset = 0
+        er = Rows(0, 0, 0)
+        if E is not None:
+            if E.shape != logits.shape:
+                raise _lib.NastHipError("noise tensor must have the shape of logits")
+            er, _ = rows_of(E)
+        elif not noise_off:
+            gen = torch.cuda.default_generators[logits.device.index]
+            seed, offset = gen.initial_seed(), gen.get_offset()
+            gen.set_offset(offset + ((logits.numel() + 3) // 4 + 3) // 4 * 4)
+        m = None
+        if mask is not None:
+            m = _c(mask.expand(logits.shape).to(torch.int64))
+        call("nast_gumbel_softmax_fwd_f32", _p(logits), lr, _p(E), er, _p(m), _p(y), yr, _p(idx), rows, V, 1.0 / tau,
+             seed & (2 ** 64 - 1), offset, 1 if noise_off else 0, _stream())
+        ctx.save_for_backward(y)
+        ctx.it = 1.0 / tau
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    def backward(ctx, gy, _gidx):
+        (y,) = ctx.saved_tensors
+        V = y.shape[-1]
+        gy = _c(gy)
+        gx = torch.empty_like(y)
+        yr, rows = rows_of(y)
+        call("nast_softmax_bwd_f32", _p(gy), yr, _p(y), yr, _p(gx), yr, rows, V, ctx.it, _stream())
+        return gx, None, None, None, None
+
+
+def gumbel_softmax_sample(logits, E=None, mask=None, tau=1.0, noise_off=False):
+    """-> (y_soft, argmax index)"""
+    return GumbelSoftmaxFn.apply(logits, E, mask, float(tau), noise_off)
+
+
+def first_eos_length(tokens, eos):
+    tokens = _c(tokens)
+    out = torch.empty(tokens.shape[0], device=tokens.device, dtype=torch.int64)
+    call("nast_first_eos_length_i64", _p(tokens), _p(out), tokens.shape[0], tokens.shape[1], int(eos), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# embedding assembly
+# ------------------------------------------------------------------------------------------------
+class EmbedFn(torch.autograd.Function):
+    """[extra rows | token + position] -> [B, n_extra + L, d]  (transformer.py:63-65, :141-148, :225-231).
+    tokens: int64 ids [B,L]  or  fp32 rows [B,L,d] already multiplied by the table (soft tokens)."""
+
+    @staticmethod
+    def forward(ctx, tokens, tok_w, pos_w, ew0, ei0, ew1, ei1):
+        hard = tokens.dtype == torch.int64
+        B, L = tokens.shape[0], tokens.shape[1]
+        d = pos_w.shape[1]
+        ne = (ew0 is not None) + (ew1 is not None)
+        tokens = _c(tokens)
+        out = torch.empty(B, ne + L, d, device=pos_w.device, dtype=F32)
+        call("nast_embed_fwd_f32", _p(out), B, L, d, ne, _p(tokens) if hard else None, _p(tok_w) if hard else None,
+             None if hard else _p(tokens), _p(pos_w), _p(ew0), _p(ei0), _p(ew1), _p(ei1), _stream())
+        ctx.save_for_backward(tokens if hard else None, ei0, ei1)
+        ctx.meta = (hard, B, L, d, ne, tok_w.shape if tok_w is not None else None, pos_w.shape,
+                    ew0.shape if ew0 is not None else None, ew1.shape if ew1 is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, ei0, ei1 = ctx.saved_tensors
+        hard, B, L, d, ne, tws, pws, e0s, e1s = ctx.meta
+        dout = _c(dout)
+        dev = dout.device
+        d_tokw = torch.zeros(tws, device=dev, dtype=F32) if (hard and ctx.needs_input_grad[1]) else None
+        d_rows = torch.empty(B, L, d, device=dev, dtype=F32) if not hard else None
+        d_pos = torch.zeros(pws, device=dev, dtype=F32)
+        d_e0 = torch.zeros(e0s, device=dev, dtype=F32) if e0s is not None else None
+        d_e1 = torch.zeros(e1s, device=dev, dtype=F32) if e1s is not None else None
+        call("nast_embed_bwd_f32", _p(dout), B, L, d, ne, _p(ids), _p(d_tokw), _p(d_rows), _p(d_pos), _p(d_e0), _p(ei0),
+             _p(d_e1), _p(ei1), _stream())
+        return (d_rows if not hard else None), d_tokw, d_pos, d_e0, None, d_e1, None
+
+
+def embed_assemble(tokens, tok_w, pos_w, extra=()):
+    """extra: up to two (weight [n,d], index [B] int64 or None) pairs placed in front of the tokens."""
+    ew0 = ei0 = ew1 = ei1 = None
+    if len(extra) > 0:
+        ew0, ei0 = extra[0]
+        ew0 = ew0.view(-1, ew0.shape[-1])
+    if len(extra) > 1:
+        ew1, ei1 = extra[1]
+        ew1 = ew1.view(-1, ew1.shape[-1])
+    return EmbedFn.apply(tokens, tok_w, pos_w, ew0, ei0, ew1, ei1)
+
+
+# ------------------------------------------------------------------------------------------------
+# alignment
+# ------------------------------------------------------------------------------------------------
+def align_costs(E, tgt_ids, src_ids=None, src_emb=None, src_unk_w=None, unk_id=3):
+    """cost0 [B,T], cost [B,T,S]   (transformer.py:396-412)"""
+    B, T = tgt_ids.shape
+    S = src_ids.shape[1] if src_ids is not None else src_emb.shape[1]
+    V, d = E.shape
+    cost0 = torch.empty(B, T, device=E.device, dtype=F32)
+    cost = torch.empty(B, T, S, device=E.device, dtype=F32)
+    stride = 0
+    if src_unk_w is not None:
+        # a strided view like soft[..., unk]: element (b,s) at base + (b*S+s)*stride
+        assert src_unk_w.dim() == 2 and src_unk_w.stride(0) == S * src_unk_w.stride(1)
+        stride = src_unk_w.stride(1)
+    call("nast_align_cost_f32", _p(_c(E)), V, d, _p(_c(tgt_ids)), _p(_c(src_ids)) if src_ids is not None else None,
+         _p(_c(src_emb)) if src_emb is not None else None, _p(src_unk_w), stride, unk_id, _p(cost0), _p(cost), B, T, S, _stream())
+    return cost0, cost
+
+
+def align_viterbi(cost0, cost, origin_length, target_length):
+    """allpos int64 [B,T+1]   (transformer.py:413-448), bit-exact given the same cost tables"""
+    B, T, S = cost.shape
+    allpos = torch.empty(B, T + 1, device=cost.device, dtype=torch.int64)
+    call("nast_align_viterbi_f32", _p(_c(cost0)), _p(_c(cost)), _p(_c(origin_length)), _p(_c(target_length)), _p(allpos),
+         B, T, S, _stream())
+    return allpos
+
+
+class AlignLSEFn(torch.autograd.Function):
+    """Soft alignment value (extension; no counterpart in the reference)."""
+
+    @staticmethod
+    def forward(ctx, cost0, cost, origin_length, target_length, tau):
+        cost0, cost = _c(cost0), _c(cost)
+        B, T, S = cost.shape
+        value = torch.empty(B, device=cost.device, dtype=F32)
+        alpha = torch.empty(B, T, S, device=cost.device, dtype=F32)
+        ol, tl = _c(origin_length), _c(target_length)
+        call("nast_align_lse_fwd_f32", _p(cost0), _p(cost), _p(ol), _p(tl), tau, _p(value), _p(alpha), B, T, S, _stream())
+        ctx.save_for_backward(cost0, cost, ol, tl, value, alpha)
+        ctx.tau = tau
+        return value
+
+    @staticmethod
+    def backward(ctx, dvalue):
+        cost0, cost, ol, tl, value, alpha = ctx.saved_tensors
+        B, T, S = cost.shape
+        dc0, dc = torch.empty_like(cost0), torch.empty_like(cost)
+        call("nast_align_lse_bwd_f32", _p(cost0), _p(cost), _p(ol), _p(tl), ctx.tau, _p(value), _p(alpha), _p(_c(dvalue)),
+             _p(dc0), _p(dc), B, T, S, _stream())
+        return dc0, dc, None, None, None
+
+
+def align_lse(cost0, cost, origin_length, target_length, tau=1.0):
+    return AlignLSEFn.apply(cost0, cost, origin_length, target_length, float(tau))
+
+
+class LPGatherFn(torch.autograd.Function):
+    """LengthPredictor candidate gather (transformer.py:471-473, :488-491, :504-505)."""
+
+    @staticmethod
+    def forward(ctx, origin_input, origin_length, allpos, eos, unk, pos_w, shift, use_stay, pos_skip0):
+        _chk(origin_input, eos, unk, pos_w)
+        origin_input, allpos, origin_length = _c(origin_input), _c(allpos), _c(origin_length)
+        eos, unk = _c(eos), _c(unk)
+        B, S1, d = origin_input.shape
+        T1 = allpos.shape[1]
+        out = torch.empty(B, T1, d, device=origin_input.device, dtype=F32)
+        call("nast_lp_gather_fwd_f32", _p(origin_input), _p(origin_length), _p(allpos), _p(eos), _p(unk), _p(pos_w), _p(out),
+             B, S1, T1, d, shift, use_stay, _stream())
+        ctx.save_for_backward(origin_length, allpos)
+        ctx.meta = (B, S1, T1, d, shift, use_stay, pos_skip0, pos_w.shape if pos_w is not None else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        origin_length, allpos = ctx.saved_tensors
+        B, S1, T1, d, shift, use_stay, pos_skip0, pws = ctx.meta
+        dout = _c(dout)
+        dev = dout.device
+        d_oin = torch.zeros(B, S1, d, device=dev, dtype=F32) if ctx.needs_input_grad[0] else None
+        d_eos = torch.zeros(d, device=dev, dtype=F32)
+        d_unk = torch.zeros(d, device=dev, dtype=F32)
+        d_pos = torch.zeros(pws, device=dev, dtype=F32) if pws is not None else None
+        call("nast_lp_gather_bwd_f32", _p(dout), _p(origin_length), _p(allpos), _p(d_oin), _p(d_eos), _p(d_unk), _p(d_pos),
+             B, S1, T1, d, shift, use_stay, pos_skip0, _stream())
+        return d_oin, None, None, d_eos, d_unk, d_pos, None, None, None
+
+
+def lp_gather(origin_input, origin_length, allpos, eos, unk, pos_w=None, shift=0, use_stay=True, pos_skip0=True):
+    return LPGatherFn.apply(origin_input, origin_length, allpos, eos, unk, pos_w, int(shift), int(use_stay), int(pos_skip0))

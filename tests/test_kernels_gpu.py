@@ -1,0 +1,244 @@
+"""GPU: each C-ABI kernel family against a plain fp32 PyTorch (CPU) statement of the same op.
+Tolerance: fp32, 1e-4 relative (north_star) unless noted; index outputs exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "needs a GPU"
+    from nast_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.cuda()
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol)
+
+
+def relclose(a, b, tol=1e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item() + 1e-30
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (70, 40, 32), (1088, 256, 256), (300, 1024, 256), (2112, 9600, 256), (33, 2, 32), (5, 7, 9)])
+def test_gemm_linear_fwd_bwd(ops, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    xr, Wr, br, rr = (t.clone().requires_grad_(True) for t in (x, W, b, res))
+    yref = torch.nn.functional.linear(xr, Wr, br) + rr
+    (yref * R).sum().backward()
+    xg, Wg, bg, rg = (dev(t).requires_grad_(True) for t in (x, W, b, res))
+    y = ops.linear(xg, Wg, bg, residual=rg)
+    (y * dev(R)).sum().backward()
+    relclose(y, yref)
+    relclose(xg.grad, xr.grad)
+    relclose(Wg.grad, Wr.grad)
+    relclose(bg.grad, br.grad)
+    relclose(rg.grad, rr.grad)
+
+
+def test_gemm_relu_and_matmul_nn(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(130, 48, generator=g)
+    W = torch.randn(72, 48, generator=g) / 7
+    b = torch.randn(72, generator=g)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    R = torch.randn(130, 72, generator=g)
+    yref = torch.relu(torch.nn.functional.linear(xr, Wr, br))
+    (yref * R).sum().backward()
+    xg, Wg, bg = (dev(t).requires_grad_(True) for t in (x, W, b))
+    y = ops.linear(xg, Wg, bg, relu=True)
+    (y * dev(R)).sum().backward()
+    relclose(y, yref); relclose(xg.grad, xr.grad); relclose(Wg.grad, Wr.grad); relclose(bg.grad, br.grad)
+    # soft tokens x table
+    s = torch.softmax(torch.randn(6, 11, 40, generator=g), -1)
+    E = torch.randn(40, 32, generator=g)
+    sr, Er = s.clone().requires_grad_(True), E.clone().requires_grad_(True)
+    R = torch.randn(6, 11, 32, generator=g)
+    (torch.matmul(sr, Er) * R).sum().backward()
+    sg, Eg = dev(s).requires_grad_(True), dev(E).requires_grad_(True)
+    y = ops.matmul_nn(sg, Eg)
+    (y * dev(R)).sum().backward()
+    relclose(y, torch.matmul(s, E)); relclose(sg.grad, sr.grad); relclose(Eg.grad, Er.grad)
+
+
+@pytest.mark.parametrize("rows,d", [(7, 32), (1088, 256), (100, 1024), (9, 48)])
+def test_layernorm(ops, rows, d):
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, d, generator=g) * 2 + 0.5
+    w = torch.rand(d, generator=g) + 0.5
+    b = torch.randn(d, generator=g)
+    R = torch.randn(rows, d, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yref = torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-6)
+    (yref * R).sum().backward()
+    xg, wg, bg = (dev(t).requires_grad_(True) for t in (x, w, b))
+    y = ops.layer_norm(xg, wg, bg)
+    (y * dev(R)).sum().backward()
+    relclose(y, yref); relclose(xg.grad, xr.grad); relclose(wg.grad, wr.grad); relclose(bg.grad, br.grad)
+
+
+def test_layernorm_row_map(ops):
+    g = torch.Generator().manual_seed(5)
+    B, n, d = 5, 9, 64
+    x = torch.randn(B, n, d, generator=g)
+    w, b = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g)
+    R = torch.randn(B, n - 1, d, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yref = torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-6)[:, 1:]
+    (yref * R).sum().backward()
+    xg, wg, bg = (dev(t).requires_grad_(True) for t in (x, w, b))
+    y = ops.layer_norm_rows(xg, wg, bg, n - 1, n, 1, B * (n - 1)).view(B, n - 1, d)
+    (y * dev(R)).sum().backward()
+    relclose(y, yref); relclose(xg.grad, xr.grad); relclose(wg.grad, wr.grad); relclose(bg.grad, br.grad)
+
+
+def ref_attention(q, k, v, mask, h):
+    B, nq, D = q.shape
+    dk = D // h
+    qh, kh, vh = (t.view(B, -1, h, dk).transpose(1, 2) for t in (q, k, v))
+    s = qh.matmul(kh.transpose(-2, -1)) / math.sqrt(dk)
+    if mask is not None:
+        s = s.masked_fill(mask, float("-inf"))
+    return torch.softmax(s, -1).matmul(vh).transpose(1, 2).contiguous().view(B, nq, D)
+
+
+@pytest.mark.parametrize("B,nq,nk,h,dk,kind", [(3, 7, 9, 4, 8, "pad"), (4, 17, 17, 4, 64, "pad"), (2, 33, 33, 4, 64, "causal"),
+                                                (2, 33, 34, 4, 64, "pad"), (2, 70, 70, 2, 64, "causal"), (1, 130, 130, 2, 64, "pad"),
+                                                (2, 1, 12, 4, 16, "none"), (2, 9, 9, 2, 32, "causal")])
+def test_attention(ops, B, nq, nk, h, dk, kind):
+    g = torch.Generator().manual_seed(B * 100 + nq)
+    D = h * dk
+    q, k, v = (torch.randn(B, n, D, generator=g) for n in (nq, nk, nk))
+    if kind == "pad":
+        lens = torch.randint(1, nk + 1, (B,), generator=g)
+        mask = (torch.arange(nk)[None] >= lens[:, None]).view(B, 1, 1, nk)
+    elif kind == "causal":
+        big = (torch.ones(nk + 3, nk + 3).tril() == 0).view(1, 1, nk + 3, nk + 3)
+        mask = big[:, :, :nq, :nk]   # non-contiguous slice, as transformer.py:497 passes it
+    else:
+        mask = None
+    R = torch.randn(B, nq, D, generator=g)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    yref = ref_attention(qr, kr, vr, mask, h)
+    (yref * R).sum().backward()
+    qg, kg, vg = (dev(t).requires_grad_(True) for t in (q, k, v))
+    y = ops.attention(qg, kg, vg, dev(mask) if mask is not None else None, h)
+    (y * dev(R)).sum().backward()
+    relclose(y, yref); relclose(qg.grad, qr.grad); relclose(kg.grad, kr.grad); relclose(vg.grad, vr.grad)
+
+
+@pytest.mark.parametrize("rows,V", [(6, 40), (33, 9600), (5, 1001), (3, 32000)])
+def test_log_softmax_and_generator(ops, rows, V):
+    g = torch.Generator().manual_seed(V)
+    x = torch.randn(rows, V, generator=g) * 3
+    R = torch.randn(rows, V, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yref = torch.log_softmax(xr, -1)
+    (yref * R).sum().backward()
+    xg = dev(x).requires_grad_(True)
+    y = ops.log_softmax(xg)
+    (y * dev(R)).sum().backward()
+    close(y, yref, 1e-5, 1e-5); relclose(xg.grad, xr.grad)
+    if V <= 9600:
+        d = 32
+        h = torch.randn(rows, d, generator=g)
+        W, b = torch.randn(V, d, generator=g) / 4, torch.randn(V, generator=g)
+        hr, Wr, br = (t.clone().requires_grad_(True) for t in (h, W, b))
+        yref = torch.log_softmax(torch.nn.functional.linear(hr, Wr, br) / 0.7, -1)
+        (yref * R).sum().backward()
+        hg, Wg, bg = (dev(t).requires_grad_(True) for t in (h, W, b))
+        y = ops.generator(hg, Wg, bg, 0.7)
+        (y * dev(R)).sum().backward()
+        close(y, yref, 1e-4, 1e-4); relclose(hg.grad, hr.grad); relclose(Wg.grad, Wr.grad); relclose(bg.grad, br.grad)
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 40), (2, 16, 9600), (4, 3, 1001)])
+def test_gumbel_softmax(ops, shape):
+    g = torch.Generator().manual_seed(shape[-1])
+    logits = torch.log_softmax(torch.randn(*shape, generator=g) * 2, -1)
+    E = torch.empty(*shape).exponential_(generator=g)
+    R = torch.randn(*shape, generator=g)
+    for tau in (1.0, 0.5):
+        lr = logits.clone().requires_grad_(True)
+        gum = torch.min(-E.log(), torch.ones(1) * 1e10)
+        yref = ((lr + gum) / tau).softmax(-1)
+        (yref * R).sum().backward()
+        lg = dev(logits).requires_grad_(True)
+        y, idx = ops.gumbel_softmax_sample(lg, dev(E), None, tau)
+        (y * dev(R)).sum().backward()
+        relclose(y, yref); relclose(lg.grad, lr.grad)
+        assert torch.equal(idx.cpu(), yref.argmax(-1))
+    # sliced (non-contiguous batch stride) input, like log_probs[:, 1:]
+    full = torch.randn(shape[0], shape[1] + 1, shape[2], generator=g)
+    y, idx = ops.gumbel_softmax_sample(dev(full)[:, 1:], dev(E), None, 1.0)
+    relclose(y, ((full[:, 1:] + torch.min(-E.log(), torch.ones(1) * 1e10))).softmax(-1))
+    # in-kernel Philox: a valid distribution, reproducible for a fixed generator state, different across calls
+    torch.cuda.manual_seed(123)
+    y1, _ = ops.gumbel_softmax_sample(dev(logits))
+    y2, _ = ops.gumbel_softmax_sample(dev(logits))
+    torch.cuda.manual_seed(123)
+    y3, _ = ops.gumbel_softmax_sample(dev(logits))
+    assert torch.allclose(y1.sum(-1).cpu(), torch.ones(shape[:-1]), atol=1e-4)
+    assert torch.equal(y1, y3) and not torch.equal(y1, y2)
+    # mask variant + noise-free variant
+    mask = (torch.rand(*shape, generator=g) > 0.3).long(); mask[..., 0] = 1
+    ym, _ = ops.gumbel_softmax_sample(dev(logits), dev(E), dev(mask), 1.0)
+    relclose(ym, (logits + torch.min(-E.log(), torch.ones(1) * 1e10)).masked_fill(mask == 0, -1e9).softmax(-1))
+    ys, _ = ops.gumbel_softmax_sample(dev(logits), None, None, 1.0, True)
+    relclose(ys, logits.softmax(-1))
+
+
+def test_gumbel_rng_statistics(ops):
+    # argmax of (logits + Gumbel) must follow softmax(logits): chi-square-ish check on a small vocabulary
+    torch.cuda.manual_seed(7)
+    p = torch.tensor([0.5, 0.25, 0.125, 0.125])
+    logits = p.log().view(1, 1, 4).expand(1, 40000, 4).contiguous()
+    _, idx = ops.gumbel_softmax_sample(dev(logits))
+    freq = torch.bincount(idx.view(-1).cpu(), minlength=4).float() / 40000
+    assert (freq - p).abs().max() < 0.01, freq
+
+
+def test_first_eos_length(ops):
+    toks = torch.tensor([[5, 6, 7, 8], [2, 5, 6, 7], [5, 6, 7, 2], [5, 2, 6, 2], [2, 2, 2, 2]])
+    assert ops.first_eos_length(dev(toks), 2).cpu().tolist() == [4, 1, 4, 2, 1]
+
+
+@pytest.mark.parametrize("soft", [False, True])
+def test_embed_assemble(ops, soft):
+    g = torch.Generator().manual_seed(9)
+    B, L, d, V = 5, 7, 32, 40
+    tokw, posw = torch.randn(V, d, generator=g), torch.randn(L + 2, d, generator=g)
+    stylew, cls = torch.randn(2, d, generator=g), torch.randn(d, generator=g)
+    style = torch.tensor([0, 1, 1, 0, 1])
+    ids = torch.randint(0, V, (B, L), generator=g)
+    rows = torch.randn(B, L, d, generator=g)
+    R = torch.randn(B, L + 2, d, generator=g)
+    tr, pr, sr, cr, rr = (t.clone().requires_grad_(True) for t in (tokw, posw, stylew, cls, rows))
+    tok = rr if soft else tr[ids]
+    yref = torch.cat([cr.view(1, 1, d).expand(B, 1, d), sr[style][:, None], tok + pr[:L][None]], 1)
+    (yref * R).sum().backward()
+    tg, pg, sg, cg, rg = (dev(t).requires_grad_(True) for t in (tokw, posw, stylew, cls, rows))
+    y = ops.embed_assemble(rg if soft else dev(ids), None if soft else tg, pg, extra=[(cg, None), (sg, dev(style))])
+    (y * dev(R)).sum().backward()
+    close(y, yref, 1e-6, 1e-6)
+    relclose(pg.grad, pr.grad); relclose(sg.grad, sr.grad); relclose(cg.grad, cr.grad)
+    if soft:
+        relclose(rg.grad, rr.grad)
+    else:
+        relclose(tg.grad, tr.grad)
