@@ -85,21 +85,22 @@ int nast_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, 
  * Fused masked multi-head attention for short sequences (LDS-staged, whole K/V of one (batch, head)
  * per workgroup).  Replaces: scaled_attention + the view/transpose/contiguous around it --
  * transformer.py:287-303.
- * q [B, nq, h*dk] (row stride ldq), k/v [B, nk, h*dk] (row strides ldk/ldv), out [B, nq, h*dk] (ldo).
+ * q [B, nq, h*dk] (row stride ldq, batch stride q_bs), k/v [B, nk, h*dk] (ldk/ldv, k_bs/v_bs),
+ * out [B, nq, h*dk] (ldo, o_bs); strides in elements, so K/V caches and projection outputs are used in place.
  * mask: uint8/bool, element (b, i, j) at mask[b*mask_bs + i*mask_qs + j], nonzero = masked (-inf);
  *       key-padding masks use mask_qs = 0, the causal mask uses mask_bs = 0; NULL = no mask.
  * lse  [B, h, nq] (log-sum-exp of the scaled, masked scores) is saved for backward.
- * Limits: dk == 64 or dk <= 64 multiple of 4; nk <= 256.
+ * Limits: dk in {8,16,32,64}; K/V + score tiles must fit 160 KiB of LDS (nk <= ~160 at dk = 64).
  * ---------------------------------------------------------------------------------------------- */
 int nast_mha_fwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask,
                      float* out, float* lse, int B, int h, int nq, int nk, int dk,
-                     int ldq, int ldk, int ldv, int ldo, int64_t mask_bs, int64_t mask_qs,
-                     float scale, void* stream);
+                     int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                     int64_t mask_bs, int64_t mask_qs, float scale, void* stream);
 int nast_mha_bwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask,
                      const float* out, const float* dout, const float* lse,
                      float* dq, float* dk_, float* dv, int B, int h, int nq, int nk, int dk,
-                     int ldq, int ldk, int ldv, int ldo, int64_t mask_bs, int64_t mask_qs,
-                     float scale, void* stream);
+                     int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                     int64_t mask_bs, int64_t mask_qs, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row kernels over the vocabulary axis (HBM-bound): one workgroup per row.
@@ -192,6 +193,18 @@ int nast_lp_gather_fwd_f32(const float* origin_input, const int64_t* origin_leng
 int nast_lp_gather_bwd_f32(const float* dout, const int64_t* origin_length, const int64_t* allpos,
                            float* d_origin_input, float* d_eos, float* d_unk, float* d_pos,
                            int B, int S1, int T1, int d, int shift, int use_stay, int pos_skip_row0, void* stream);
+
+/* One greedy skip-decoding step (transformer.py:549-567, z_decode_mode == "max"), one wavefront per sentence:
+ *   logit[0] = qh . kunk / sqrt(d) + lin(hid)[0];  logit[j] = qh . KC[b, now+j] / sqrt(d) + lin(hid)[j], j=1..3
+ *   step 0: logit[0] = -1e9 and logit[j] -= 1e9 where source position j is padding (:553-555)
+ *   delta = first argmax; now = min(now + delta, S1); allpos[b, step+1] = now;
+ *   x_next[b] = (delta == 0 ? unk : cand_in[b, now]) + pos_w[step+1]      (next decoder input, :535-540)
+ * qh = wq(hidden), hid = hidden [B,d]; KC = wk(cand_in) [B,S1+5,d]; kunk = wk(unk) [d]; cand_in [B,S1+5,d];
+ * lin_w [4,d], lin_b [4]; now_pos int64 [B] (in/out); allpos int64 [B, ldp].                          */
+int nast_lp_step_f32(const float* qh, const float* hid, const float* KC, const float* kunk,
+                     const float* lin_w, const float* lin_b, const float* cand_in, const float* unk,
+                     const float* pos_w, const int64_t* origin_length, int64_t* now_pos, int64_t* allpos,
+                     float* x_next, int B, int S1, int d, int step, int ldp, int write_next, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser side (seq2seq.py:536-537, :637-638): multi-tensor L2 norm + clip + Adam in few launches.

@@ -38,8 +38,8 @@ SIGNATURES = {
     "nast_gemm_f32": [C.POINTER(GemmDesc), _i, c_fp],
     "nast_layernorm_fwd_f32": [c_fp] * 6 + [_i, _i, _f, _i, _i, _i, c_fp],
     "nast_layernorm_bwd_f32": [c_fp] * 9 + [_i, _i, _i, _i, _i, _i, c_fp],
-    "nast_mha_fwd_f32": [c_fp] * 6 + [_i] * 9 + [_i64, _i64, _f, c_fp],
-    "nast_mha_bwd_f32": [c_fp] * 10 + [_i] * 9 + [_i64, _i64, _f, c_fp],
+    "nast_mha_fwd_f32": [c_fp] * 6 + [_i] * 9 + [_i64] * 6 + [_f, c_fp],
+    "nast_mha_bwd_f32": [c_fp] * 10 + [_i] * 9 + [_i64] * 6 + [_f, c_fp],
     "nast_log_softmax_fwd_f32": [c_fp, Rows, c_fp, Rows, _i, _i, _f, c_fp],
     "nast_log_softmax_bwd_f32": [c_fp, Rows, c_fp, Rows, c_fp, Rows, _i, _i, _f, c_fp],
     "nast_gumbel_softmax_fwd_f32": [c_fp, Rows, c_fp, Rows, c_fp, c_fp, Rows, c_fp, _i, _i, _f, _u64, _u64, _i, c_fp],
@@ -53,6 +53,7 @@ SIGNATURES = {
     "nast_align_lse_bwd_f32": [c_fp] * 4 + [_f] + [c_fp] * 5 + [_i, _i, _i, c_fp],
     "nast_lp_gather_fwd_f32": [c_fp] * 7 + [_i] * 6 + [c_fp],
     "nast_lp_gather_bwd_f32": [c_fp] * 7 + [_i] * 7 + [c_fp],
+    "nast_lp_step_f32": [c_fp] * 13 + [_i] * 6 + [c_fp],
     "nast_multi_sqnorm_f32": [c_fp, c_fp, _i, c_fp, c_fp],
     "nast_multi_adam_f32": [c_fp] * 5 + [_i, c_fp] + [_f] * 8 + [c_fp],
     "nast_prof_begin": [_i],

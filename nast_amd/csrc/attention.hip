@@ -41,8 +41,8 @@ template <int DK, int TPR>
 __global__ __launch_bounds__(256) void nast_mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v, const uint8_t* __restrict__ mask,
                                                            float* __restrict__ out, float* __restrict__ lse, int h, int nq,
-                                                           int nk, int ldq, int ldk, int ldv, int ldo, int64_t mask_bs,
-                                                           int64_t mask_qs, float scale) {
+                                                           int nk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs,
+                                                           int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale) {
   constexpr int R = 256 / TPR, LD = AttnGeom<DK>::LD, CPT = DK / TPR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x / h, head = blockIdx.x % h;
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_kernel(const float* __restri
   float* Ks = smem;
   float* Vs = Ks + nk * LD;
   float* Ps = Vs + nk * LD;
-  stage_rows<DK>(Ks, k + (int64_t)b * nk * ldk + head * DK, nk, ldk);
-  stage_rows<DK>(Vs, v + (int64_t)b * nk * ldv + head * DK, nk, ldv);
+  stage_rows<DK>(Ks, k + b * k_bs + head * DK, nk, ldk);
+  stage_rows<DK>(Vs, v + b * v_bs + head * DK, nk, ldv);
   __syncthreads();
   const int i = threadIdx.x / TPR, sub = threadIdx.x % TPR;
   for (int q0 = 0; q0 < nq; q0 += R) {
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_kernel(const float* __restri
     const bool valid = qi < nq;
     float qr[DK];
     if (valid) {
-      const float* qp = q + ((int64_t)b * nq + qi) * ldq + head * DK;
+      const float* qp = q + b * q_bs + (int64_t)qi * ldq + head * DK;
 #pragma unroll
       for (int c = 0; c < DK; c += 4) {
         const float4 t = *reinterpret_cast<const float4*>(qp + c);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_kernel(const float* __restri
       for (int c = 0; c < CPT; ++c) acc[c] = fmaf(p, vr[c], acc[c]);
     }
     if (valid) {
-      float* op = out + ((int64_t)b * nq + qi) * ldo + head * DK + sub * CPT;
+      float* op = out + b * o_bs + (int64_t)qi * ldo + head * DK + sub * CPT;
 #pragma unroll
       for (int c = 0; c < CPT; ++c) op[c] = acc[c] * inv;
     }
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void nast_mha_bwd_kernel(const float* __restri
                                                            const float* __restrict__ dout, const float* __restrict__ lse,
                                                            float* __restrict__ dq, float* __restrict__ dk_, float* __restrict__ dv,
                                                            int h, int nq, int nk, int ldq, int ldk, int ldv, int ldo,
+                                                           int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                                                            int64_t mask_bs, int64_t mask_qs, float scale) {
   constexpr int R = 256 / TPR, LD = AttnGeom<DK>::LD, CPT = DK / TPR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -130,14 +131,14 @@ __global__ __launch_bounds__(256) void nast_mha_bwd_kernel(const float* __restri
   float* Gs = Qs + R * LD;      // dO chunk
   float* Ps = Gs + R * LD;      // P  [R][nkp]
   float* Ss = Ps + R * nkp;     // dS [R][nkp]
-  stage_rows<DK>(Ks, k + (int64_t)b * nk * ldk + head * DK, nk, ldk);
-  stage_rows<DK>(Vs, v + (int64_t)b * nk * ldv + head * DK, nk, ldv);
+  stage_rows<DK>(Ks, k + b * k_bs + head * DK, nk, ldk);
+  stage_rows<DK>(Vs, v + b * v_bs + head * DK, nk, ldv);
   const int i = threadIdx.x / TPR, sub = threadIdx.x % TPR;
   for (int q0 = 0; q0 < nq; q0 += R) {
     const int rows = min(R, nq - q0);
     __syncthreads();   // previous chunk done with Qs/Gs/Ps/Ss (and K/V staged on the first pass)
-    stage_rows<DK>(Qs, q + ((int64_t)b * nq + q0) * ldq + head * DK, rows, ldq);
-    stage_rows<DK>(Gs, dout + ((int64_t)b * nq + q0) * ldo + head * DK, rows, ldo);
+    stage_rows<DK>(Qs, q + b * q_bs + (int64_t)q0 * ldq + head * DK, rows, ldq);
+    stage_rows<DK>(Gs, dout + b * o_bs + (int64_t)q0 * ldo + head * DK, rows, ldo);
     __syncthreads();
     const int qi = q0 + i;
     const bool valid = i < rows;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void nast_mha_bwd_kernel(const float* __restri
         for (int c = 0; c < CPT; ++c) acc[c] = fmaf(s, kr[c], acc[c]);
       }
       if (valid) {
-        float* op = dq + ((int64_t)b * nq + qi) * ldq + head * DK + sub * CPT;
+        float* op = dq + b * q_bs + (int64_t)qi * ldq + head * DK + sub * CPT;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) op[c] = acc[c];
       }
@@ -204,8 +205,8 @@ __global__ __launch_bounds__(256) void nast_mha_bwd_kernel(const float* __restri
           av[c] = fmaf(p, gv[c], av[c]);
         }
       }
-      float* kp = dk_ + ((int64_t)b * nk + j) * ldk + head * DK + sub * CPT;
-      float* vp = dv + ((int64_t)b * nk + j) * ldv + head * DK + sub * CPT;
+      float* kp = dk_ + b * k_bs + (int64_t)j * ldk + head * DK + sub * CPT;
+      float* vp = dv + b * v_bs + (int64_t)j * ldv + head * DK + sub * CPT;
       if (q0 == 0) {
 #pragma unroll
         for (int c = 0; c < CPT; ++c) { kp[c] = ak[c]; vp[c] = av[c]; }
@@ -229,8 +230,8 @@ static int check_common(const char* name, int B, int h, int nq, int nk, int dk, 
 
 template <int DK>
 static int launch_fwd(const float* q, const float* k, const float* v, const uint8_t* mask, float* out, float* lse, int B,
-                      int h, int nq, int nk, int ldq, int ldk, int ldv, int ldo, int64_t mbs, int64_t mqs, float scale,
-                      hipStream_t s) {
+                      int h, int nq, int nk, int ldq, int ldk, int ldv, int ldo, int64_t qb, int64_t kb, int64_t vb, int64_t ob,
+                      int64_t mbs, int64_t mqs, float scale, hipStream_t s) {
   const int LD = AttnGeom<DK>::LD;
   int tpr = nq <= 32 ? 8 : 4;
   size_t lds = ((size_t)2 * nk * LD + (size_t)(256 / tpr) * (nk + 1)) * 4;
@@ -239,11 +240,11 @@ static int launch_fwd(const float* q, const float* k, const float* v, const uint
   if (tpr == 8) {
     auto kern = nast_mha_fwd_kernel<DK, 8>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, v, mask, out, lse, h, nq, nk, ldq, ldk, ldv, ldo, mbs, mqs, scale);
+    hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, v, mask, out, lse, h, nq, nk, ldq, ldk, ldv, ldo, qb, kb, vb, ob, mbs, mqs, scale);
   } else {
     auto kern = nast_mha_fwd_kernel<DK, 4>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, v, mask, out, lse, h, nq, nk, ldq, ldk, ldv, ldo, mbs, mqs, scale);
+    hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, v, mask, out, lse, h, nq, nk, ldq, ldk, ldv, ldo, qb, kb, vb, ob, mbs, mqs, scale);
   }
   NAST_CHECK_LAUNCH("nast_mha_fwd_f32");
   return NAST_OK;
@@ -252,7 +253,8 @@ static int launch_fwd(const float* q, const float* k, const float* v, const uint
 template <int DK>
 static int launch_bwd(const float* q, const float* k, const float* v, const uint8_t* mask, const float* dout,
                       const float* lse, float* dq, float* dk_, float* dv, int B, int h, int nq, int nk, int ldq, int ldk,
-                      int ldv, int ldo, int64_t mbs, int64_t mqs, float scale, hipStream_t s) {
+                      int ldv, int ldo, int64_t qb, int64_t kb, int64_t vb, int64_t ob, int64_t mbs, int64_t mqs, float scale,
+                      hipStream_t s) {
   const int LD = AttnGeom<DK>::LD;
   auto need = [&](int R) { return ((size_t)2 * nk * LD + (size_t)2 * R * LD + (size_t)2 * R * (nk + 1)) * 4; };
   int tpr = (nq > 32 && need(64) <= 64 * 1024) ? 4 : 8;
@@ -261,35 +263,35 @@ static int launch_bwd(const float* q, const float* k, const float* v, const uint
   if (tpr == 8) {
     auto kern = nast_mha_bwd_kernel<DK, 8>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, v, mask, dout, lse, dq, dk_, dv, h, nq, nk, ldq, ldk, ldv, ldo, mbs, mqs, scale);
+    hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, v, mask, dout, lse, dq, dk_, dv, h, nq, nk, ldq, ldk, ldv, ldo, qb, kb, vb, ob, mbs, mqs, scale);
   } else {
     auto kern = nast_mha_bwd_kernel<DK, 4>;
-    hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, v, mask, dout, lse, dq, dk_, dv, h, nq, nk, ldq, ldk, ldv, ldo, mbs, mqs, scale);
+    hipLaunchKernelGGL(kern, dim3(B * h), dim3(256), lds, s, q, k, v, mask, dout, lse, dq, dk_, dv, h, nq, nk, ldq, ldk, ldv, ldo, qb, kb, vb, ob, mbs, mqs, scale);
   }
   NAST_CHECK_LAUNCH("nast_mha_bwd_f32");
   return NAST_OK;
 }
 
 extern "C" int nast_mha_fwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask, float* out, float* lse,
-                                int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t mask_bs,
-                                int64_t mask_qs, float scale, void* stream) {
+                                int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs,
+                                int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, void* stream) {
   int rc = check_common("nast_mha_fwd_f32", B, h, nq, nk, dk, ldq, ldk, ldv, ldo);
   if (rc) return rc;
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(q && k && v && out && lse, "nast_mha_fwd_f32: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
   switch (dk) {
-    case 8: return launch_fwd<8>(q, k, v, mask, out, lse, B, h, nq, nk, ldq, ldk, ldv, ldo, mask_bs, mask_qs, scale, s);
-    case 16: return launch_fwd<16>(q, k, v, mask, out, lse, B, h, nq, nk, ldq, ldk, ldv, ldo, mask_bs, mask_qs, scale, s);
-    case 32: return launch_fwd<32>(q, k, v, mask, out, lse, B, h, nq, nk, ldq, ldk, ldv, ldo, mask_bs, mask_qs, scale, s);
-    default: return launch_fwd<64>(q, k, v, mask, out, lse, B, h, nq, nk, ldq, ldk, ldv, ldo, mask_bs, mask_qs, scale, s);
+    case 8: return launch_fwd<8>(q, k, v, mask, out, lse, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
+    case 16: return launch_fwd<16>(q, k, v, mask, out, lse, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
+    case 32: return launch_fwd<32>(q, k, v, mask, out, lse, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
+    default: return launch_fwd<64>(q, k, v, mask, out, lse, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
   }
 }
 
 extern "C" int nast_mha_bwd_f32(const float* q, const float* k, const float* v, const uint8_t* mask, const float* out,
                                 const float* dout, const float* lse, float* dq, float* dk_, float* dv, int B, int h, int nq,
-                                int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t mask_bs, int64_t mask_qs,
-                                float scale, void* stream) {
+                                int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
+                                int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, void* stream) {
   (void)out;
   int rc = check_common("nast_mha_bwd_f32", B, h, nq, nk, dk, ldq, ldk, ldv, ldo);
   if (rc) return rc;
@@ -297,9 +299,9 @@ extern "C" int nast_mha_bwd_f32(const float* q, const float* k, const float* v, 
   NAST_REQUIRE(q && k && v && dout && lse && dq && dk_ && dv, "nast_mha_bwd_f32: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
   switch (dk) {
-    case 8: return launch_bwd<8>(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, ldq, ldk, ldv, ldo, mask_bs, mask_qs, scale, s);
-    case 16: return launch_bwd<16>(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, ldq, ldk, ldv, ldo, mask_bs, mask_qs, scale, s);
-    case 32: return launch_bwd<32>(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, ldq, ldk, ldv, ldo, mask_bs, mask_qs, scale, s);
-    default: return launch_bwd<64>(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, ldq, ldk, ldv, ldo, mask_bs, mask_qs, scale, s);
+    case 8: return launch_bwd<8>(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
+    case 16: return launch_bwd<16>(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
+    case 32: return launch_bwd<32>(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
+    default: return launch_bwd<64>(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
   }
 }

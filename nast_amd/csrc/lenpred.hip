@@ -1,0 +1,72 @@
+// LengthPredictor greedy skip decoding, one step (transformer.py:549-567): 4-way skip logits, first-step
+// masking, argmax, position update and the gather of the next decoder input -- one wavefront per sentence,
+// replacing ~15 tiny ATen launches (gather/einsum/linear/max/min/compare) per decoding step.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void nast_lp_step_kernel(const float* __restrict__ qh, const float* __restrict__ hid,
+                                                           const float* __restrict__ KC, const float* __restrict__ kunk,
+                                                           const float* __restrict__ lin_w, const float* __restrict__ lin_b,
+                                                           const float* __restrict__ cand_in, const float* __restrict__ unk,
+                                                           const float* __restrict__ pos_w, const int64_t* __restrict__ olen_,
+                                                           int64_t* __restrict__ now_pos, int64_t* __restrict__ allpos,
+                                                           float* __restrict__ x_next, int B, int S1, int d, int step,
+                                                           int ldp, float sqrt_d, int write_next) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int NC = S1 + 5;                      // rows of the candidate table (transformer.py:472-473)
+  const int64_t now = now_pos[b];
+  const float* q = qh + (int64_t)b * d;
+  const float* hrow = hid + (int64_t)b * d;
+  float dot[4] = {0.f, 0.f, 0.f, 0.f}, lin[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = lane; c < d; c += 64) {
+    const float qv = q[c], hv = hrow[c];
+    dot[0] = fmaf(qv, kunk[c], dot[0]);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) dot[j] = fmaf(qv, KC[((int64_t)b * NC + now + j) * d + c], dot[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lin[j] = fmaf(hv, lin_w[j * d + c], lin[j]);
+  }
+  float logit[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) logit[j] = wave_sum(dot[j]) / sqrt_d + (wave_sum(lin[j]) + lin_b[j]);
+  if (step == 0) {                             // :553-555
+    const int64_t ol = olen_[b];
+    logit[0] = -1e9f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) logit[j] = logit[j] - ((j >= 1 && j - 1 >= ol) ? 1.f : 0.f) * 1e9f;
+  }
+  int delta = 0;
+  float best = logit[0];
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (logit[j] > best) { best = logit[j]; delta = j; }   // first maximum wins (:559)
+  int64_t nxt = now + delta;
+  if (nxt > S1) nxt = S1;                      // :565  (origin_seqlen + 1)
+  if (lane == 0) {
+    now_pos[b] = nxt;
+    allpos[(int64_t)b * ldp + step + 1] = nxt;
+  }
+  if (write_next) {
+    const float* src = (delta == 0) ? unk : cand_in + ((int64_t)b * NC + nxt) * d;   // :535-537
+    const float* pw = pos_w + (int64_t)(step + 1) * d;
+    float* dst = x_next + (int64_t)b * d;
+    for (int c = lane; c < d; c += 64) dst[c] = src[c] + pw[c];
+  }
+}
+
+extern "C" int nast_lp_step_f32(const float* qh, const float* hid, const float* KC, const float* kunk, const float* lin_w,
+                                const float* lin_b, const float* cand_in, const float* unk, const float* pos_w,
+                                const int64_t* origin_length, int64_t* now_pos, int64_t* allpos, float* x_next, int B, int S1,
+                                int d, int step, int ldp, int write_next, void* stream) {
+  NAST_REQUIRE(B >= 0 && S1 >= 1 && d >= 1 && step >= 0 && ldp >= step + 2, "nast_lp_step_f32: bad sizes");
+  if (B == 0) return NAST_OK;
+  NAST_REQUIRE(qh && hid && KC && kunk && lin_w && lin_b && cand_in && unk && pos_w && origin_length && now_pos && allpos,
+               "nast_lp_step_f32: NULL pointer");
+  NAST_REQUIRE(!write_next || x_next, "nast_lp_step_f32: x_next NULL");
+  hipLaunchKernelGGL(nast_lp_step_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, qh, hid, KC, kunk, lin_w, lin_b,
+                     cand_in, unk, pos_w, origin_length, now_pos, allpos, x_next, B, S1, d, step, ldp, sqrtf((float)d),
+                     write_next);
+  NAST_CHECK_LAUNCH("nast_lp_step_f32");
+  return NAST_OK;
+}

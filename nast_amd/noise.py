@@ -1,0 +1,143 @@
+"""Input noise of the self-reconstruction pass (reference: styletransformer/noise.py:8-230).
+
+Host-side (numpy) restatement: the noise layer runs once per f_step on [L, B] integer ids, its outputs are
+INPUTS of the GPU hot path (a device-side version is a "next" row).  Random
+numbers are drawn from numpy's global generator in the same order and shapes as the reference, so a run with
+the same numpy seed produces the same blank / dropout decisions; the added words come from torch.multinomial
+as in the reference.  Every stage is a pure function of its random draws (`*_apply`), which is what the
+tests exercise.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+
+class NoiseLayer(nn.Module):
+    def __init__(self, word_blank, word_dropout, word_shuffle, word_repeat, word_add, *,
+                 keep_go=True, keep_eos=True, max_length, dm):
+        super().__init__()
+        self.blank_prob, self.dropout_prob = word_blank, word_dropout
+        self.shuffle_weight, self.repeat_prob, self.add_prob = word_shuffle, word_repeat, word_add
+        self.pad_index, self.blank_index, self.eos_index = dm.pad_id, dm.unk_id, dm.eos_id
+        self.keep_go, self.keep_eos = keep_go, keep_eos
+        self.max_length = max_length
+        self.dm = dm
+        self.register_buffer("cnt", torch.tensor(self._add_distribution(dm), dtype=torch.float))
+
+    @staticmethod
+    def _add_distribution(dm):
+        """tf-idf weighted unigram distribution per style used by word_add (noise.py:33-58)."""
+        V = dm.frequent_vocab_size
+        freq, doc = [], np.zeros(V)
+        n_sent = 0
+        for domain in (0, 1):
+            sents = dm.get_all_batch(f"train_{domain}")["sent"]
+            tf = np.zeros(V)
+            df = np.zeros(V)
+            for s in sents:
+                ids = np.asarray(s, dtype=np.int64)
+                np.add.at(tf, ids, 1)
+                df[np.unique(ids)] += 1
+            tf[:4] = 0
+            freq.append(tf / tf.sum())
+            doc += df / len(sents)
+            n_sent += len(sents)
+        idf = np.maximum(np.log(0.3 / (doc + 1e-10)), 0)
+        out = []
+        for tf in freq:
+            p = tf * idf
+            out.append(p / p.sum())
+        return np.array(out)
+
+    # ---- stages as pure functions of their random draws ------------------------------------
+    def blank_apply(self, x, l, u):
+        """x [seq,B] ids, l [B], u [seq,B] uniforms: positions before the final token are replaced by <unk>
+        where u < blank_prob (noise.py:103-135 with keep_go=False, keep_eos=True)."""
+        keep = u >= self.blank_prob
+        pos = np.arange(x.shape[0])[:, None]
+        if self.keep_go:
+            keep[0] = True
+        keep |= pos >= (l[None, :] - 1 if self.keep_eos else l[None, :])
+        return np.where(keep, x, self.blank_index), l
+
+    def add_apply(self, x, l, u, new_words):
+        """Insert words: u [M-1,B] uniforms (u < add_prob -> the slot holds an inserted word),
+        new_words [M,B] candidates (noise.py:76-101)."""
+        M = self.max_length
+        B = x.shape[1]
+        orig = np.concatenate([np.ones((1, B), dtype=bool), u >= self.add_prob], 0)        # True: slot shows a source word
+        src = np.cumsum(orig, 0) - 1                                                       # which source word
+        src = np.maximum(src, np.arange(-M, 0)[:, None] + l[None, :])                      # the tail must still fit
+        past_end = src >= l[None, :]
+        l_new = (~past_end).sum(0)
+        for i in range(B):
+            if l_new[i] > 1 and not orig[l_new[i] - 1, i]:
+                l_new[i] -= 1
+        src = np.minimum(src, l[None, :] - 1)
+        out = np.take_along_axis(x, src, 0)
+        out = np.where(orig, out, new_words)
+        out = np.where(past_end, self.eos_index, out)
+        return out[:l_new.max()], l_new
+
+    def dropout_apply(self, x, l, u_keep, u_repeat, pick):
+        """Drop (u_keep < dropout_prob) / repeat words, re-append <eos>, re-pad (noise.py:137-194).
+        pick(n) -> index in [0,n) used when every word of a sentence was dropped."""
+        M = self.max_length
+        B = x.shape[1]
+        keep = u_keep >= self.dropout_prob
+        adv = np.concatenate([np.zeros((1, B), dtype=np.int64), np.cumsum(u_repeat >= self.repeat_prob, 0)], 0)
+        sents = []
+        for i in range(B):
+            n = l[i] - 1 if x[l[i] - 1, i] == self.eos_index else l[i]
+            words = x[:n, i]
+            kept = words[keep[:n, i]]
+            if kept.size == 0:
+                kept = words[pick(n):][:1]
+            idx = np.maximum(adv[:, i], np.arange(-M, 0) + kept.size)
+            out = kept[idx[idx < kept.size]].tolist()
+            if len(out) < M and out[-1] != self.eos_index:
+                out.append(self.eos_index)
+            sents.append(out)
+        l2 = np.array([len(s) for s in sents], dtype=np.int64)
+        x2 = np.full((l2.max(), B), self.pad_index, dtype=np.int64)
+        for i, s in enumerate(sents):
+            x2[:len(s), i] = s
+        return x2, l2
+
+    def shuffle_apply(self, x, l, noise):
+        """Local shuffle: sort positions by index + noise (noise.py:196-230)."""
+        out = x.copy()
+        for i in range(x.shape[1]):
+            s = 1 if self.keep_go else 0
+            t = l[i] - 1 if self.keep_eos else l[i]
+            perm = (np.arange(t - s) + noise[s:t, i]).argsort()
+            out[s:t, i] = x[s:t, i][perm]
+        return out, l
+
+    # ---- reference call signature -------------------------------------------------------------
+    def forward(self, words, lengths, rev_domain):
+        """words [seq,B] int64, lengths [B], rev_domain [B] -> (noisy words [seq',B], lengths [B]) on words.device.
+        Stage order and draw order follow noise.py:60-74 (shuffle, blank, add, dropout)."""
+        dev = words.device
+        x = words.detach().cpu().numpy()
+        l = lengths.detach().cpu().numpy().astype(np.int64)
+        M = self.max_length
+        if self.shuffle_weight != 0:
+            assert self.shuffle_weight > 1
+            x, l = self.shuffle_apply(x, l, np.random.uniform(0, self.shuffle_weight, size=x.shape))
+        if self.blank_prob != 0:
+            assert 0 < self.blank_prob <= 1
+            x, l = self.blank_apply(x, l, np.random.rand(*x.shape))
+        if self.add_prob != 0:
+            assert self.add_prob < 1
+            u = np.random.rand(M - 1, x.shape[1])
+            dist = self.cnt[rev_domain.to(self.cnt.device)]
+            new_words = torch.multinomial(dist, M, True).transpose(0, 1).cpu().numpy()
+            x, l = self.add_apply(x, l, u, new_words)
+        if self.dropout_prob != 0 or self.repeat_prob != 0:
+            assert self.dropout_prob < 1 and self.repeat_prob < 1
+            assert not self.keep_go and self.keep_eos
+            u_keep = np.random.rand(M, x.shape[1])
+            u_rep = np.random.rand(M - 1, x.shape[1])
+            x, l = self.dropout_apply(x, l, u_keep, u_rep, lambda n: np.random.randint(0, n))
+        return torch.from_numpy(np.ascontiguousarray(x)).to(dev), torch.from_numpy(l).to(dev)

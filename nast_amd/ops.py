@@ -147,14 +147,16 @@ def _mask_args(mask, B, nq, nk):
 
 
 def mha_fwd(q, k, v, mask, h):
-    """q [B,nq,D], k/v [B,nk,D] contiguous -> out [B,nq,D], lse [B,h,nq]"""
+    """q [B,nq,D], k/v [B,nk,D] (last dim contiguous, any row/batch strides) -> out [B,nq,D], lse [B,h,nq]"""
     B, nq, D = q.shape
     nk = k.shape[1]
     dk = D // h
-    out = torch.empty_like(q)
+    out = torch.empty(B, nq, D, device=q.device, dtype=F32)
     lse = torch.empty(B, h, nq, device=q.device, dtype=F32)
     m, bs, qs = _mask_args(mask, B, nq, nk)
-    call("nast_mha_fwd_f32", _p(q), _p(k), _p(v), _p(m), _p(out), _p(lse), B, h, nq, nk, dk, D, D, D, D, bs, qs,
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    call("nast_mha_fwd_f32", _p(q), _p(k), _p(v), _p(m), _p(out), _p(lse), B, h, nq, nk, dk,
+         q.stride(1), k.stride(1), v.stride(1), D, q.stride(0), k.stride(0), v.stride(0), nq * D, bs, qs,
          1.0 / math.sqrt(dk), _stream())
     return out, lse
 
@@ -166,7 +168,7 @@ def mha_bwd(q, k, v, mask, h, out, dout, lse):
     dq, dk_, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     m, bs, qs = _mask_args(mask, B, nq, nk)
     call("nast_mha_bwd_f32", _p(q), _p(k), _p(v), _p(m), _p(out), _p(dout), _p(lse), _p(dq), _p(dk_), _p(dv),
-         B, h, nq, nk, dk, D, D, D, D, bs, qs, 1.0 / math.sqrt(dk), _stream())
+         B, h, nq, nk, dk, D, D, D, D, nq * D, nk * D, nk * D, nq * D, bs, qs, 1.0 / math.sqrt(dk), _stream())
     return dq, dk_, dv
 
 

@@ -1,0 +1,290 @@
+"""Trainer of NAST-StyTrans on the HIP modules: the reference's `Seq2seq` surface for the generator /
+discriminator training steps (reference: styletransformer/seq2seq.py, cited as seq2seq.py:line).
+
+In scope: __init__ (optimiser split), f_step, d_step, approx, get_lengths, pretrain, train, calc_temperature,
+_preprocess_batch, get_next_batch, get_next_mix_batch.  Out of scope (needs cotk metrics + the RoBERTa
+classifier): evaluate / train_process / test_process -> NotImplementedError.
+
+Data parallelism (new; the reference is single-device): when torch.distributed is initialised, gradients of the
+parameter group being stepped are averaged across ranks by nast_amd.ddp.GradReducer (bucketed all-reduce on
+RCCL, fired once per step during the LAST backward so that it overlaps with it) before clip + Adam.
+"""
+import numpy as np
+import torch
+from torch import nn, optim
+from torch.nn.utils import clip_grad_norm_
+
+from . import ops
+from .ddp import GradReducer
+from .transformer import Network
+from .utils import Storage, BaseModel, LongTensor, cuda, generateMask
+from .utils.gumbel import gumbel_soft_and_index
+
+
+def item(x, default_val=0):
+    return x.item() if x is not None else default_val
+
+
+class Seq2seq(BaseModel):
+    def __init__(self, param):
+        args = param.args
+        net = Network(param)
+        if args.radam:
+            raise NotImplementedError("--radam: utils/optimizer.py is out of scope (SURVEY.md section 2.1 row 8)")
+        self.optimizer_F = optim.Adam(net.get_parameters_by_name("F"), lr=args.lr_F, weight_decay=args.L2)
+        self.optimizer_D = optim.Adam(net.get_parameters_by_name("D"), lr=args.lr_D, weight_decay=args.L2)
+        super().__init__(param, net, {"optimizer_F": self.optimizer_F, "optimizer_D": self.optimizer_D})
+        self.reducer_F = GradReducer(list(self.net.model_F.parameters()))
+        self.reducer_D = GradReducer(list(self.net.model_D.parameters()))
+
+    # ---- batches (seq2seq.py:108-164) ---------------------------------------------------------
+    def _preprocess_batch(self, data0, data1):
+        incoming = Storage()
+        incoming.data = data = Storage()
+        empty = {"sent": np.zeros((0, 1), dtype=int), "sent_length": []}
+        data0 = Storage(data0 if data0 is not None else empty)
+        data1 = Storage(data1 if data1 is not None else empty)
+        n0, n1 = data0.sent.shape[0], data1.sent.shape[0]
+        data.batch_size = n0 + n1
+        data.seqlen = max(data0.sent.shape[1], data1.sent.shape[1]) - 1
+        sent = np.zeros((data.batch_size, data.seqlen), dtype=np.int64)
+        if n0:
+            sent[:n0, :data0.sent.shape[1] - 1] = np.asarray(data0.sent)[:, 1:]      # remove <go>
+        if n1:
+            sent[n0:, :data1.sent.shape[1] - 1] = np.asarray(data1.sent)[:, 1:]
+        data.sent = LongTensor(sent)
+        lens = np.concatenate([data0.sent_length, data1.sent_length], axis=0).astype(int)
+        data.sent_length = LongTensor(lens) - 1
+        data.domain = LongTensor([0] * n0 + [1] * n1)
+        return incoming
+
+    def get_next_batch(self, dm, key, domain, restart=True, raw=False):
+        data = dm.get_next_batch(key + "_" + str(domain))
+        if data is None:
+            if not restart:
+                return None
+            dm.restart(key + "_" + str(domain))
+            return self.get_next_batch(dm, key, domain, False, raw)
+        if raw:
+            return data
+        return self._preprocess_batch(data, None) if domain == 0 else self._preprocess_batch(None, data)
+
+    def get_next_mix_batch(self, dm, key):
+        return self._preprocess_batch(self.get_next_batch(dm, key, 0, raw=True), self.get_next_batch(dm, key, 1, raw=True))
+
+    # ---- schedules (seq2seq.py:166-280) ----------------------------------------------------------
+    def calc_temperature(self, temperature_config, step):
+        num = len(temperature_config)
+        for i in range(num):
+            t_a, s_a = temperature_config[i]
+            if i == num - 1:
+                return t_a
+            t_b, s_b = temperature_config[i + 1]
+            if s_a <= step < s_b:
+                k = (step - s_a) / (s_b - s_a)
+                return (1 - k) * t_a + k * t_b
+
+    def pretrain(self, batch_num):
+        self.net.model_F.train(); self.net.model_D.train()
+        args, dm = self.param.args, self.param.volatile.dm
+        dm.restart('train_0', args.batch_size); dm.restart('train_1', args.batch_size)
+        hist = []
+        for i in range(batch_num):
+            self.now_batch += 1
+            incoming = self.get_next_mix_batch(dm, 'train')
+            hist.append(self.f_step(incoming, temperature=1.0, cyc_rec_enable=False, use_inference_z=True))
+            if (i + 1) % 10 == 0:
+                m = np.mean(np.array(hist, dtype=float), 0)
+                hist = []
+                print('[iter: {}] slf_loss:{:.4f}, rec_loss:{:.4f}, slf_length_loss:{:.4f}'.format(i + 1, m[0], m[1], m[3]))
+
+    def train(self, batch_num):
+        self.net.model_F.train(); self.net.model_D.train()
+        args, dm = self.param.args, self.param.volatile.dm
+        dm.restart('train_0', args.batch_size); dm.restart('train_1', args.batch_size)
+        d_hist, f_hist = [], []
+        for _ in range(batch_num):
+            self.now_batch += 1
+            temperature = self.calc_temperature(args.temperature_config, self.now_batch)
+            use_z = (self.now_batch - args.F_pretrain_iter) > args.pre_z_batch
+            for _ in range(args.iter_D):
+                d_hist.append(self.d_step(self.get_next_mix_batch(dm, 'train'), temperature=temperature, use_inference_z=use_z))
+            for _ in range(args.iter_F):
+                f_hist.append(self.f_step(self.get_next_mix_batch(dm, 'train'), temperature=temperature, use_inference_z=use_z))
+            if self.now_batch % args.log_steps == 0:
+                f = np.mean(np.array(f_hist, dtype=float), 0)
+                print(('[iter {}] d_adv_loss: {:.4f}  f_slf_loss: {:.4f}  f_cyc_loss: {:.4f}  f_adv_loss: {:.4f}  '
+                       'f_slf_length_loss: {:.4f}  f_cyc_length_loss: {:.4f}  temp: {:.4f}  f_slf_gen_error: {:.4f} '
+                       'f_cyc_gen_error: {:.4f}').format(self.now_batch, np.mean(d_hist), f[0], f[1], f[2], f[3], f[4],
+                                                          temperature, f[5], f[6]))
+
+    def evaluate(self, *a, **k):
+        raise NotImplementedError("evaluate needs cotk metrics + the RoBERTa classifier (out of scope, SURVEY 2.1)")
+
+    train_process = test_process = evaluate
+
+    # ---- the step --------------------------------------------------------------------------------
+    def approx(self, logits, mode):
+        """seq2seq.py:407-414"""
+        if mode == "soft":
+            return logits.exp()
+        if mode == "gumbel":
+            return gumbel_soft_and_index(logits)[0]
+        raise NotImplementedError()
+
+    def _approx_with_index(self, logits, mode):
+        if mode == "gumbel":
+            return gumbel_soft_and_index(logits)      # the kernel's argmax == soft_tokens.argmax(-1)
+        soft = self.approx(logits, mode)
+        return soft, soft.argmax(-1)
+
+    def get_lengths(self, tokens, eos_idx):
+        """seq2seq.py:545-549: first <eos> index + 1, capped at the width."""
+        return ops.first_eos_length(tokens, eos_idx)
+
+    def _length_loss(self, losses, inp_lengths, batch_size):
+        if len(losses.shape) <= 1:
+            return losses
+        # generateMask on the device (the reference builds it on the host: seq2seq.py:461, a D2H sync)
+        mask = (torch.arange(losses.shape[1], device=losses.device).unsqueeze(0) < (inp_lengths + 1).unsqueeze(1)).float()
+        return (losses * mask).sum() / batch_size * self.args.length_factor
+
+    def f_step(self, incoming, temperature, cyc_rec_enable=True, *, use_inference_z):
+        """seq2seq.py:416-543 -> (slf, cyc, adv, slf_len, cyc_len, slf_gen_err, cyc_gen_err) as Python floats."""
+        self.net.model_D.eval()
+        dm = self.param.volatile.dm
+        pad_idx, eos_idx = dm.pad_id, dm.eos_id
+        args = self.args
+        loss_fn = nn.NLLLoss(reduction='none')
+
+        inp_tokens = incoming.data.sent
+        inp_lengths = incoming.data.sent_length
+        raw_styles = incoming.data.domain
+        rev_styles = 1 - raw_styles
+        batch_size = inp_tokens.size(0)
+        token_mask = (inp_tokens != pad_idx).float()
+
+        self.optimizer_F.zero_grad()
+
+        noise_inp_tokens, noise_inp_lengths = self.net.noiseLayer(inp_tokens.transpose(0, 1), inp_lengths, rev_domain=rev_styles)
+        noise_inp_tokens = noise_inp_tokens.transpose(0, 1).contiguous()
+
+        model_F = self.net.model_F
+        slf_log_probs, _, slf_length_losses, slf_gen_error, _ = model_F(
+            noise_inp_tokens, noise_inp_lengths, inp_tokens, inp_lengths, raw_styles,
+            generate=False, differentiable_decode=False, temperature=temperature, use_inference_z=use_inference_z)
+        slf_rec_loss = loss_fn(slf_log_probs.transpose(1, 2), inp_tokens) * token_mask
+        slf_rec_loss = slf_rec_loss.sum() / batch_size
+        slf_rec_loss = slf_rec_loss * args.slf_factor
+
+        last_backward = not cyc_rec_enable
+        if last_backward:
+            self.reducer_F.arm()
+        if args.use_learnable:
+            slf_rec_length_loss = self._length_loss(slf_length_losses, inp_lengths, batch_size)
+            (slf_rec_loss + slf_rec_length_loss).backward()
+        else:
+            slf_rec_length_loss = None
+            slf_rec_loss.backward()
+
+        if not cyc_rec_enable:                                                 # seq2seq.py:471-474 (no clipping here)
+            self.reducer_F.finish()
+            self.optimizer_F.step()
+            self.net.model_D.train()
+            return slf_rec_loss.item(), 0, 0, item(slf_rec_length_loss), 0, item(slf_gen_error), 0
+
+        gen_log_probs, gen_lengths, _, _, _ = model_F(
+            inp_tokens, inp_lengths, None, None, rev_styles,
+            generate=True, differentiable_decode=True, temperature=temperature, use_inference_z=use_inference_z)
+        gen_soft_tokens, gen_idx = self._approx_with_index(gen_log_probs, args.gen_approx_mode)
+        if not args.use_learnable:
+            gen_lengths = self.get_lengths(gen_idx, eos_idx)
+
+        cyc_log_probs, _, cyc_length_losses, cyc_gen_error, _ = model_F(
+            gen_soft_tokens, gen_lengths, inp_tokens, inp_lengths, raw_styles,
+            generate=False, differentiable_decode=False, temperature=temperature, use_inference_z=use_inference_z)
+        cyc_rec_loss = loss_fn(cyc_log_probs.transpose(1, 2), inp_tokens) * token_mask
+        cyc_rec_loss = cyc_rec_loss.sum() / batch_size
+        cyc_rec_loss = cyc_rec_loss * args.cyc_factor
+        cyc_rec_length_loss = self._length_loss(cyc_length_losses, inp_lengths, batch_size) if args.use_learnable else None
+
+        adv_log_probs = self.net.model_D(gen_soft_tokens, gen_lengths, rev_styles)
+        if args.discriminator_method == 'Multi':
+            adv_labels = rev_styles + 1
+        else:
+            adv_labels = torch.ones_like(rev_styles)
+        adv_loss = loss_fn(adv_log_probs, adv_labels)
+        adv_factor = (raw_styles == 0) * args.fw_adv_factor + (raw_styles == 1) * args.bw_adv_factor
+        adv_loss = (adv_loss * adv_factor).sum() / batch_size
+
+        self.reducer_F.arm()
+        if args.use_learnable:
+            (cyc_rec_loss + adv_loss + cyc_rec_length_loss).backward()
+        else:
+            (cyc_rec_loss + adv_loss).backward()
+        self.reducer_F.finish()
+
+        self.last_grad_norm = clip_grad_norm_(self.net.model_F.parameters(), 5)
+        self.optimizer_F.step()
+        self.net.model_D.train()
+
+        return slf_rec_loss.item(), cyc_rec_loss.item(), adv_loss.item(), \
+            item(slf_rec_length_loss), item(cyc_rec_length_loss), item(slf_gen_error), item(cyc_gen_error)
+
+    def d_step(self, incoming, temperature, *, use_inference_z):
+        """seq2seq.py:551-642 -> adv_loss (float)"""
+        dm = self.param.volatile.dm
+        self.net.model_F.eval()
+        eos_idx = dm.eos_id
+        args = self.args
+        loss_fn = nn.NLLLoss(reduction='none')
+        inp_tokens = incoming.data.sent
+        inp_lengths = incoming.data.sent_length
+        raw_styles = incoming.data.domain
+        rev_styles = 1 - raw_styles
+        batch_size = inp_tokens.size(0)
+        model_F, model_D = self.net.model_F, self.net.model_D
+
+        with torch.no_grad():
+            raw_gen_log_probs, raw_gen_lengths, _, _, _ = model_F(
+                inp_tokens, inp_lengths, None, None, raw_styles, generate=True, differentiable_decode=True,
+                temperature=temperature, use_inference_z=use_inference_z)
+            rev_gen_log_probs, rev_gen_lengths, _, _, _ = model_F(
+                inp_tokens, inp_lengths, None, None, rev_styles, generate=True, differentiable_decode=True,
+                temperature=temperature, use_inference_z=use_inference_z)
+
+        raw_gen_soft_tokens, raw_idx = self._approx_with_index(raw_gen_log_probs, args.dis_approx_mode)
+        if not args.use_learnable:
+            raw_gen_lengths = self.get_lengths(raw_idx, eos_idx)
+        rev_gen_soft_tokens, rev_idx = self._approx_with_index(rev_gen_log_probs, args.dis_approx_mode)
+        if not args.use_learnable:
+            rev_gen_lengths = self.get_lengths(rev_idx, eos_idx)
+
+        if args.discriminator_method == 'Multi':
+            gold_log_probs = model_D(inp_tokens, inp_lengths)
+            gold_labels = raw_styles + 1
+            gen_log_probs = torch.cat((model_D(raw_gen_soft_tokens, raw_gen_lengths),
+                                       model_D(rev_gen_soft_tokens, rev_gen_lengths)), 0)
+            gen_labels = torch.cat((raw_styles + 1, torch.zeros_like(rev_styles)), 0)
+        else:
+            gold_log_probs = torch.cat((model_D(inp_tokens, inp_lengths, raw_styles),
+                                        model_D(inp_tokens, inp_lengths, rev_styles)), 0)
+            gold_labels = torch.cat((torch.ones_like(raw_styles), torch.zeros_like(rev_styles)), 0)
+            gen_log_probs = torch.cat((model_D(raw_gen_soft_tokens, raw_gen_lengths, raw_styles),
+                                       model_D(rev_gen_soft_tokens, rev_gen_lengths, rev_styles)), 0)
+            gen_labels = torch.cat((torch.ones_like(raw_styles), torch.zeros_like(rev_styles)), 0)
+
+        adv_log_probs = torch.cat((gold_log_probs, gen_log_probs), 0)
+        adv_labels = torch.cat((gold_labels, gen_labels), 0)
+        adv_loss = loss_fn(adv_log_probs, adv_labels)
+        assert len(adv_loss.size()) == 1
+        adv_loss = adv_loss.sum() / batch_size
+
+        self.optimizer_D.zero_grad()
+        self.reducer_D.arm()
+        adv_loss.backward()
+        self.reducer_D.finish()
+        self.last_grad_norm = clip_grad_norm_(model_D.parameters(), 5)
+        self.optimizer_D.step()
+        model_F.train()
+        return adv_loss.item()

@@ -1,0 +1,550 @@
+"""NAST-StyTrans generator / discriminator on hand-written gfx950 kernels.
+
+Same classes, constructor arguments, forward signatures and state_dict keys as the reference's
+styletransformer/transformer.py (cited below as transformer.py:line), so checkpoints and callers are
+interchangeable.  The arithmetic is done by libnast_hip.so through nast_amd.ops:
+
+  * every sublayer `x + f(LN(x))` is ONE autograd node (LayerNorm -> grouped QKV GEMM on MFMA -> fused
+    masked attention -> output GEMM with bias+residual epilogue), instead of ~25 ATen calls;
+  * head split / merge are strides inside the attention kernel, no transpose/contiguous copies;
+  * style/cls rows, token gather (or soft-token GEMM) and positions are assembled by one kernel;
+  * the decoder's final LayerNorm + generator run on rows 1.. only (row 0 is discarded at transformer.py:103);
+  * the alignment DP runs one wavefront per sentence; greedy skip decoding keeps a real K/V cache.
+
+Remaining PyTorch glue (index arithmetic on [B, T] integer tensors and the 4-way skip-logit einsum /
+cross-entropy of LengthPredictor's teacher-forced branch) is listed in DESIGN.md.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import ops
+from .noise import NoiseLayer
+from .utils.network_helper import BaseNetwork
+
+
+class Network(BaseNetwork):
+    """transformer.py:9-16 -- attribute names model_F / model_D drive the optimiser split."""
+
+    def __init__(self, param):
+        super().__init__(param)
+        args = self.param.args
+        self.model_F = StyleTransformer(param)
+        self.model_D = Discriminator(param)
+        self.noiseLayer = NoiseLayer(args.word_blank, args.word_dropout, args.word_shuffle, args.word_repeat,
+                                     args.word_add, keep_go=False, max_length=args.max_length, dm=param.volatile.dm)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers with the reference's initialisation (transformer.py:332-350)
+# ------------------------------------------------------------------------------------------------
+class HipLinear(nn.Linear):
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class HipLayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias)
+
+
+def Linear(in_features, out_features, bias=True, uniform=True):
+    m = HipLinear(in_features, out_features, bias)
+    if uniform:
+        nn.init.xavier_uniform_(m.weight)
+    else:
+        nn.init.xavier_normal_(m.weight)
+    if bias:
+        nn.init.constant_(m.bias, 0.)
+    return m
+
+
+def Embedding(num_embeddings, embedding_dim, padding_idx=None):
+    m = nn.Embedding(num_embeddings, embedding_dim, padding_idx=padding_idx)
+    nn.init.xavier_uniform_(m.weight)
+    # Reference quirk kept for init parity (transformer.py:345): weight[None] is the whole
+    # matrix, so with padding_idx=None every embedding starts at exactly 0.
+    nn.init.constant_(m.weight[padding_idx], 0)
+    return m
+
+
+def LayerNorm(embedding_dim, eps=1e-6):
+    assert eps == 1e-6
+    return HipLayerNorm(embedding_dim, eps)
+
+
+def _pad_mask(lengths, width, extra):
+    """[B,1,1,extra+width] bool, True = masked (transformer.py:56-61, :135-139, :459-461)."""
+    B = lengths.shape[0]
+    m = torch.arange(width, device=lengths.device).unsqueeze(0) >= lengths.unsqueeze(-1)
+    if extra:
+        m = torch.cat((torch.zeros(B, extra, dtype=torch.bool, device=lengths.device), m), 1)
+    return m.view(B, 1, 1, extra + width)
+
+
+# ------------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------------
+def scaled_attention(query, key, value, mask):
+    """transformer.py:296-303 on [B,h,n,dk] tensors -> (attn_feature, None).
+    The attention matrix is never materialised by the fused kernel, so the second return value is None."""
+    B, h, nq, dk = query.shape
+    q, k, v = (t.transpose(1, 2).reshape(B, -1, h * dk) for t in (query, key, value))
+    out = ops.attention(q, k, v, mask, h)
+    return out.view(B, nq, h, dk).transpose(1, 2), None
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, d_model, h, dropout):
+        super().__init__()
+        assert d_model % h == 0
+        self.d_k = d_model // h
+        self.h = h
+        self.head_projs = nn.ModuleList([HipLinear(d_model, d_model) for _ in range(3)])
+        self.fc = HipLinear(d_model, d_model)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, query, key, value, mask):
+        """transformer.py:284-294"""
+        q, k, v = [l(x) for x, l in zip((query, key, value), self.head_projs)]
+        return self.fc(ops.attention(q, k, v, mask, self.h))
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_model, dropout):
+        super().__init__()
+        self.mlp = nn.Sequential(Linear(d_model, 4 * d_model), nn.ReLU(inplace=True), nn.Dropout(dropout),
+                                 Linear(4 * d_model, d_model))
+        _require_no_dropout(dropout)
+
+    def forward(self, x):
+        h = ops.linear(x, self.mlp[0].weight, self.mlp[0].bias, relu=True)
+        return self.mlp[3](h)
+
+
+def _require_no_dropout(p):
+    if p != 0:
+        raise NotImplementedError("the HIP path implements the reference configuration dropout=0 (run.py:139)")
+
+
+class SublayerConnection(nn.Module):
+    def __init__(self, d_model, dropout):
+        super().__init__()
+        self.layer_norm = LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+        _require_no_dropout(dropout)
+
+    def forward(self, x, sublayer):
+        return x + sublayer(self.layer_norm(x))                      # transformer.py:324-326
+
+    def incremental_forward(self, x, sublayer):
+        return x[:, -1:] + sublayer(self.layer_norm(x))              # transformer.py:328-330
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, d_model, h, dropout):
+        super().__init__()
+        self.self_attn = MultiHeadAttention(d_model, h, dropout)
+        self.pw_ffn = PositionwiseFeedForward(d_model, dropout)
+        self.sublayer = nn.ModuleList([SublayerConnection(d_model, dropout) for _ in range(2)])
+
+    def forward(self, x, mask):
+        x = ops.attn_sublayer(x, None, mask, self.self_attn.h, self.sublayer[0].layer_norm, self.self_attn)
+        return ops.ffn_sublayer(x, self.sublayer[1].layer_norm, self.pw_ffn)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, d_model, h, dropout):
+        super().__init__()
+        self.self_attn = MultiHeadAttention(d_model, h, dropout)
+        self.src_attn = MultiHeadAttention(d_model, h, dropout)
+        self.pw_ffn = PositionwiseFeedForward(d_model, dropout)
+        self.sublayer = nn.ModuleList([SublayerConnection(d_model, dropout) for _ in range(3)])
+
+    def forward(self, x, memory, src_mask, tgt_mask):
+        h = self.self_attn.h
+        x = ops.attn_sublayer(x, None, tgt_mask, h, self.sublayer[0].layer_norm, self.self_attn)
+        x = ops.attn_sublayer(x, memory, src_mask, h, self.sublayer[1].layer_norm, self.src_attn)
+        return ops.ffn_sublayer(x, self.sublayer[2].layer_norm, self.pw_ffn)
+
+    def incremental_forward(self, x, memory, src_mask, tgt_mask, prev_states=None):
+        """transformer.py:259-272 with the same state convention (lists of layer inputs)."""
+        new_states = []
+        m = memory
+        x = torch.cat((prev_states[0], x), 1) if prev_states else x
+        new_states.append(x)
+        x = self.sublayer[0].incremental_forward(x, lambda x: self.self_attn(x[:, -1:], x, x, tgt_mask))
+        x = torch.cat((prev_states[1], x), 1) if prev_states else x
+        new_states.append(x)
+        x = self.sublayer[1].incremental_forward(x, lambda x: self.src_attn(x[:, -1:], m, m, src_mask))
+        x = torch.cat((prev_states[2], x), 1) if prev_states else x
+        new_states.append(x)
+        x = self.sublayer[2].incremental_forward(x, lambda x: self.pw_ffn(x[:, -1:]))
+        return x, new_states
+
+
+class Encoder(nn.Module):
+    def __init__(self, num_layers, d_model, vocab_size, h, dropout):
+        super().__init__()
+        self.layers = nn.ModuleList([EncoderLayer(d_model, h, dropout) for _ in range(num_layers)])
+        self.norm = LayerNorm(d_model)
+
+    def forward(self, x, mask, rows=None):
+        """transformer.py:163-171.  rows=(grp, grp_stride, grp_off, rows_out): normalise only those rows."""
+        assert x.size(1) == mask.size(-1)
+        y = x
+        for layer in self.layers:
+            y = layer(y, mask)
+        if rows is not None:
+            return ops.layer_norm_rows(y, self.norm.weight, self.norm.bias, *rows)
+        return self.norm(y)
+
+
+class Generator(nn.Module):
+    def __init__(self, d_model, vocab_size):
+        super().__init__()
+        self.proj = nn.Linear(d_model, vocab_size)
+
+    def forward(self, x, temperature):
+        return ops.generator(x, self.proj.weight, self.proj.bias, temperature)   # transformer.py:213-214
+
+
+class Decoder(nn.Module):
+    def __init__(self, num_layers, d_model, vocab_size, h, dropout):
+        super().__init__()
+        self.layers = nn.ModuleList([DecoderLayer(d_model, h, dropout) for _ in range(num_layers)])
+        self.norm = LayerNorm(d_model)
+        self.generator = Generator(d_model, vocab_size)
+
+    def forward(self, x, memory, src_mask, tgt_mask, temperature, skip_first=False):
+        """transformer.py:180-188.  skip_first=True returns log-probs for positions 1.. only
+        (what StyleTransformer keeps, transformer.py:103) without computing row 0."""
+        assert x.size(1) == tgt_mask.size(-1)
+        y = x
+        for layer in self.layers:
+            y = layer(y, memory, src_mask, tgt_mask)
+        B, n, d = y.shape
+        if skip_first:
+            z = ops.layer_norm_rows(y, self.norm.weight, self.norm.bias, n - 1, n, 1, B * (n - 1))
+            return self.generator(z, temperature).view(B, n - 1, -1)
+        return self.generator(self.norm(y), temperature)
+
+
+class EmbeddingLayer(nn.Module):
+    def __init__(self, dm, d_model, max_length, pad_idx, learned_pos_embed, wordvec=None):
+        super().__init__()
+        self.token_embed = Embedding(dm.frequent_vocab_size, d_model)
+        self.pos_embed = Embedding(max_length, d_model)
+        self.vocab_size = dm.frequent_vocab_size
+        if wordvec is not None:
+            self.token_embed = nn.Embedding.from_pretrained(torch.tensor(wordvec, dtype=torch.float32))
+
+    def soft_rows(self, x):
+        """[B,L,V] soft tokens -> [B,L,d] = x @ token_embed.weight (transformer.py:229), MFMA GEMM."""
+        return ops.matmul_nn(x, self.token_embed.weight)
+
+    def forward(self, x, pos):
+        """transformer.py:225-231.  `pos` must be the leading positions 0..L-1 (the only use in the reference)."""
+        tok = x if x.dim() == 2 else self.soft_rows(x)
+        return ops.embed_assemble(tok, self.token_embed.weight if x.dim() == 2 else None, self.pos_embed.weight)
+
+    def assemble(self, x, extra, soft_rows=None):
+        """[extra rows | embed(x, 0..L-1)] in one kernel (replaces torch.cat((style_emb, embed(..)), 1))."""
+        if x.dim() == 2:
+            return ops.embed_assemble(x, self.token_embed.weight, self.pos_embed.weight, extra)
+        rows = soft_rows if soft_rows is not None else self.soft_rows(x)
+        return ops.embed_assemble(rows, None, self.pos_embed.weight, extra)
+
+
+# ------------------------------------------------------------------------------------------------
+# StyleTransformer / Discriminator
+# ------------------------------------------------------------------------------------------------
+class StyleTransformer(nn.Module):
+    check_lengths = True   # the reference asserts max(inp_lengths) <= width (a host sync); set False to skip
+
+    def __init__(self, param):
+        super().__init__()
+        self.param = param
+        config = args = self.args = param.args
+        dm = param.volatile.dm
+        self.max_length = config.max_length
+        self.eos_idx = dm.eos_id
+        self.pad_idx = dm.pad_id
+        self.style_embed = Embedding(config.num_styles, config.d_model)
+        self.embed = EmbeddingLayer(dm, config.d_model, config.max_length, self.pad_idx, config.learned_pos_embed)
+        self.sos_token = nn.Parameter(torch.randn(config.d_model))   # dead parameter kept for checkpoints (:41)
+        self.encoder = Encoder(config.num_layers, config.d_model, dm.frequent_vocab_size, config.h, config.dropout)
+        self.decoder = Decoder(config.num_layers, config.d_model, dm.frequent_vocab_size, config.h, config.dropout)
+        if args.use_learnable:
+            self.length_predictor = LengthPredictor(param)
+
+    def forward(self, inp_tokens, inp_lengths, gold_tokens, gold_lengths, style,
+                generate=False, differentiable_decode=False, temperature=1.0, *, use_inference_z):
+        """transformer.py:48-103 -> (log_probs[:,1:], tgt_lengths, length_loss, gen_error, allpos)"""
+        batch_size = inp_tokens.size(0)
+        max_enc_len = inp_tokens.size(1)
+        if self.check_lengths:
+            assert torch.max(inp_lengths) <= inp_tokens.shape[1]
+        assert max_enc_len <= self.max_length
+
+        src_mask = _pad_mask(inp_lengths, max_enc_len, 1)
+        soft_rows = self.embed.soft_rows(inp_tokens) if inp_tokens.dim() == 3 else None
+        enc_input = self.embed.assemble(inp_tokens, [(self.style_embed.weight, style)], soft_rows)
+        memory = self.encoder(enc_input, src_mask)
+
+        if self.args.decoder_input == "encoded":
+            dec_input_emb = memory
+        elif self.args.decoder_input == "raw":
+            dec_input_emb = enc_input
+        else:
+            raise NotImplementedError()
+
+        if self.args.use_learnable:
+            if generate:
+                dec_input_emb, tgt_lengths, allpos = self.length_predictor(
+                    dec_input_emb, inp_lengths, embed=self.embed, use_inference_z=use_inference_z)
+                length_loss = None
+                gen_error = None
+            else:
+                dec_input_emb, tgt_lengths, length_loss, gen_error = self.length_predictor(
+                    dec_input_emb, inp_lengths, inp_tokens, gold_tokens, gold_lengths, embed=self.embed,
+                    use_inference_z=use_inference_z, origin_soft_rows=soft_rows)
+                allpos = None
+            tgt_mask = _pad_mask(tgt_lengths, dec_input_emb.size(1) - 1, 1)
+        else:
+            tgt_mask = src_mask
+            tgt_lengths = length_loss = gen_error = allpos = None
+
+        log_probs = self.decoder(dec_input_emb, memory, src_mask, tgt_mask, temperature, skip_first=True)
+        return log_probs, tgt_lengths, length_loss, gen_error, allpos
+
+
+class Discriminator(nn.Module):
+    def __init__(self, param):
+        super().__init__()
+        self.param = param
+        self.args = config = param.args
+        dm = self.param.volatile.dm
+        self.pad_idx = dm.pad_id
+        self.style_embed = Embedding(config.num_styles, config.d_model)
+        self.embed = EmbeddingLayer(dm, config.d_model, config.max_length, self.pad_idx, config.learned_pos_embed)
+        self.cls_token = nn.Parameter(torch.randn(config.d_model))
+        self.encoder = Encoder(config.num_layers, config.d_model, dm.frequent_vocab_size, config.h, config.dropout)
+        self.classifier = Linear(config.d_model, config.num_classes)
+
+    def forward(self, inp_tokens, inp_lengths, style=None):
+        """transformer.py:130-153"""
+        B = inp_tokens.size(0)
+        num_extra = 1 if style is None else 2
+        L = inp_tokens.size(1)
+        mask = _pad_mask(inp_lengths, L, num_extra)
+        extra = [(self.cls_token, None)]
+        if style is not None:
+            extra.append((self.style_embed.weight, style))
+        enc_input = self.embed.assemble(inp_tokens, extra)
+        # only row 0 (the cls position) of the final LayerNorm is consumed (transformer.py:151)
+        feats = self.encoder(enc_input, mask, rows=(1, L + num_extra, 0, B))
+        logits = self.classifier(feats)
+        return ops.log_softmax(logits)
+
+
+# ------------------------------------------------------------------------------------------------
+# LengthPredictor
+# ------------------------------------------------------------------------------------------------
+class HiddenDecoder(nn.Module):
+    def __init__(self, num_layers, d_model, h, dropout):
+        super().__init__()
+        self.layers = nn.ModuleList([DecoderLayer(d_model, h, dropout) for _ in range(num_layers)])
+        self.norm = LayerNorm(d_model)
+
+    def forward(self, x, memory, src_mask, tgt_mask):
+        """transformer.py:359-364 -- NB: no final LayerNorm here (the reference's train/inference asymmetry)."""
+        assert x.size(1) == tgt_mask.size(-1)
+        y = x
+        for layer in self.layers:
+            y = layer(y, memory, src_mask, tgt_mask)
+        return y
+
+    def incremental_forward(self, x, memory, src_mask, tgt_mask, prev_states=None):
+        """transformer.py:366-377 (state-list API; the fast path is `KVCacheDecoder` below)."""
+        y = x
+        new_states = []
+        for i, layer in enumerate(self.layers):
+            y, sub = layer.incremental_forward(y, memory, src_mask, tgt_mask, prev_states[i] if prev_states else None)
+            new_states.append(sub)
+        new_states.append(torch.cat((prev_states[-1], y), 1) if prev_states else y)
+        y = self.norm(new_states[-1])[:, -1:]
+        return y, new_states
+
+
+class KVCacheDecoder:
+    """Step-wise evaluation of a HiddenDecoder under no_grad with a real K/V cache.
+
+    Equivalent to HiddenDecoder.incremental_forward (which re-normalises and re-projects the whole prefix
+    at every step, transformer.py:263-271): keys/values of position j depend only on the layer input at j,
+    so they are projected once and appended to a [B, max_steps, d] cache that the attention kernel reads in
+    place (batch stride = max_steps*d).  Cross-attention K/V of `memory` are projected once for all layers
+    in one grouped GEMM launch."""
+
+    def __init__(self, dec, memory, src_mask, max_steps):
+        self.dec, self.src_mask = dec, src_mask
+        B, ne, d = memory.shape
+        self.B, self.d, self.h = B, d, dec.layers[0].self_attn.h
+        dev = memory.device
+        nl = len(dec.layers)
+        self.kc = torch.empty(nl, B, max_steps, d, device=dev)
+        self.vc = torch.empty(nl, B, max_steps, d, device=dev)
+        self.mk = torch.empty(nl, B, ne, d, device=dev)
+        self.mv = torch.empty(nl, B, ne, d, device=dev)
+        mem2 = memory.reshape(-1, d)
+        descs = []
+        for i, layer in enumerate(dec.layers):
+            p = layer.src_attn.head_projs
+            descs.append(ops.d_fwd(mem2, p[1].weight, self.mk[i].view(-1, d), bias=p[1].bias))
+            descs.append(ops.d_fwd(mem2, p[2].weight, self.mv[i].view(-1, d), bias=p[2].bias))
+        ops.gemm(descs)
+        self.max_steps = max_steps
+
+    def step(self, x, k):
+        """x [B,d] = input of position k -> hidden [B,d] (after the final LayerNorm, transformer.py:376)."""
+        B, d, h = self.B, self.d, self.h
+        L = self.max_steps
+        for i, layer in enumerate(self.dec.layers):
+            sa, ca = layer.self_attn, layer.src_attn
+            z, _, _ = ops.ln_fwd(x, layer.sublayer[0].layer_norm.weight, layer.sublayer[0].layer_norm.bias)
+            q = torch.empty(B, d, device=x.device)
+            kslot, vslot = self.kc[i, :, k], self.vc[i, :, k]        # [B,d] views, row stride L*d
+            p = sa.head_projs
+            dk_, dv_ = ops.d_fwd(z, p[1].weight, kslot, bias=p[1].bias), ops.d_fwd(z, p[2].weight, vslot, bias=p[2].bias)
+            dk_.ldc = dv_.ldc = L * d
+            ops.gemm([ops.d_fwd(z, p[0].weight, q, bias=p[0].bias), dk_, dv_])
+            a, _ = ops.mha_fwd(q.view(B, 1, d), self.kc[i, :, :k + 1], self.vc[i, :, :k + 1], None, h)
+            x1 = torch.empty_like(x)
+            ops.gemm([ops.d_fwd(a.view(B, d), sa.fc.weight, x1, bias=sa.fc.bias, residual=x)])
+            z, _, _ = ops.ln_fwd(x1, layer.sublayer[1].layer_norm.weight, layer.sublayer[1].layer_norm.bias)
+            ops.gemm([ops.d_fwd(z, ca.head_projs[0].weight, q, bias=ca.head_projs[0].bias)])
+            a, _ = ops.mha_fwd(q.view(B, 1, d), self.mk[i], self.mv[i], self.src_mask, h)
+            x2 = torch.empty_like(x)
+            ops.gemm([ops.d_fwd(a.view(B, d), ca.fc.weight, x2, bias=ca.fc.bias, residual=x1)])
+            z, _, _ = ops.ln_fwd(x2, layer.sublayer[2].layer_norm.weight, layer.sublayer[2].layer_norm.bias)
+            f = layer.pw_ffn.mlp
+            hmid = torch.empty(B, f[0].weight.shape[0], device=x.device)
+            ops.gemm([ops.d_fwd(z, f[0].weight, hmid, bias=f[0].bias, relu=True)])
+            x = torch.empty_like(x2)
+            ops.gemm([ops.d_fwd(hmid, f[3].weight, x, bias=f[3].bias, residual=x2)])
+        y, _, _ = ops.ln_fwd(x, self.dec.norm.weight, self.dec.norm.bias)
+        return y
+
+
+class LengthPredictor(nn.Module):
+    def __init__(self, param):
+        super().__init__()
+        self.param = param
+        self.args = args = param.args
+        self.pos_embed = Embedding(args.max_length + 1, args.d_model, padding_idx=0)
+        self.decoder = HiddenDecoder(3, args.d_model, args.h, args.dropout)
+        self.max_skip = 4
+        self.sqrt_d_model = np.sqrt(self.args.d_model)
+        self.linear = HipLinear(args.d_model, self.max_skip)
+        self.wq = HipLinear(args.d_model, args.d_model)
+        self.wk = HipLinear(args.d_model, args.d_model)
+
+    # -- alignment DP -------------------------------------------------------------------------
+    def match(self, origin_token, origin_length, target_token, target_length, embed, origin_soft_rows=None):
+        """transformer.py:394-449 -> allpos int64 [B, T+1].  Cost tables + Viterbi run in two kernels
+        (one wavefront per target row / per sentence); indices are bit-exact given the same costs."""
+        unk_id = self.param.volatile.dm.unk_id
+        E = embed.token_embed.weight.detach()
+        with torch.no_grad():
+            if origin_token.dim() == 2:
+                cost0, cost = ops.align_costs(E, target_token, src_ids=origin_token, unk_id=unk_id)
+            else:
+                # soft source: (p with p[unk] folded into p[0]) @ E == p @ E + p[unk] * (E[0] - E[unk]);
+                # p @ E is the embedding GEMM the encoder input already needed (re-used when given)
+                rows = origin_soft_rows.detach() if origin_soft_rows is not None else ops.matmul_nn(origin_token.detach(), E)
+                cost0, cost = ops.align_costs(E, target_token, src_emb=rows, src_unk_w=origin_token.detach()[..., unk_id],
+                                              unk_id=unk_id)
+            return ops.align_viterbi(cost0, cost, origin_length, target_length)
+
+    # -- forward ------------------------------------------------------------------------------
+    def forward(self, origin_input, origin_length, origin_token=None, target_token=None, target_length=None, embed=None,
+                *, use_inference_z, origin_soft_rows=None):
+        """transformer.py:452-582.  origin_input [B,S+1,d] is the encoder memory (style token first)."""
+        dm = self.param.volatile.dm
+        batch_size = origin_input.shape[0]
+        S1 = origin_input.shape[1]
+        d = self.args.d_model
+        dev = origin_input.device
+        eos_embed = embed.token_embed.weight[dm.eos_id]
+        unk_embed = embed.token_embed.weight[dm.unk_id]
+        src_mask = _pad_mask(origin_length, S1 - 1, 1)
+        memory = origin_input
+
+        if target_token is not None:
+            if not use_inference_z:                                           # :480-484
+                assert (origin_length == target_length).sum() == batch_size
+                z = torch.zeros(1, dtype=torch.float, device=dev)[0]
+                return origin_input, target_length, z, z.clone()
+            allpos = self.match(origin_token, origin_length, target_token, target_length, embed, origin_soft_rows)
+            T1 = target_token.shape[1] + 1
+            # aligned decoder input (:488-491) and its positional variant (:493) from one gather each
+            dec_input = ops.lp_gather(origin_input, origin_length, allpos, eos_embed, unk_embed, None, 0, True)
+            dec_input_new = ops.lp_gather(origin_input, origin_length, allpos, eos_embed, unk_embed, self.pos_embed.weight, 0, True)
+            Lm = self.args.max_length + 1
+            causal = (torch.ones((Lm, Lm), device=dev).tril() == 0).view(1, 1, Lm, Lm)   # :463-464
+            hidden = self.decoder(dec_input_new, memory, src_mask, causal[:, :, :T1, :T1])
+            # skip logits (:504-507): wk is linear, so wk(candidates)[allpos+j] == wk applied once per source row
+            cand_idx = torch.arange(S1 + 5, device=dev).unsqueeze(0).expand(batch_size, -1)
+            cand_in = ops.lp_gather(origin_input, origin_length, cand_idx, eos_embed, unk_embed, None, 0, False)
+            KC = self.wk(cand_in)                                             # [B,S1+5,d]
+            kunk = self.wk(unk_embed.view(1, d))                              # [1,d]
+            qh = self.wq(hidden)                                              # [B,T1,d]
+            idx = allpos.unsqueeze(-1) + torch.arange(1, self.max_skip, device=dev)                  # [B,T1,3]
+            selK = torch.gather(KC, 1, idx.view(batch_size, -1, 1).expand(-1, -1, d)).view(batch_size, T1, self.max_skip - 1, d)
+            l0 = torch.matmul(qh, kunk.t())                                                          # [B,T1,1]
+            lr = torch.einsum("bld,bljd->blj", qh, selK)
+            logits = torch.cat((l0, lr), -1) / self.sqrt_d_model
+            logits = logits + self.linear(hidden)
+            target = torch.cat([allpos[:, 1:], origin_length.unsqueeze(-1) + 1], dim=1) - allpos     # :509
+            gen_err = (target >= 4).sum().float() / target.shape[0]                                  # :511
+            target = torch.clamp(target, max=3)
+            length_loss = F.cross_entropy(logits.transpose(1, 2), target, reduction="none")         # :517
+            return dec_input, target_length, length_loss, gen_err
+
+        if not use_inference_z:
+            return origin_input, origin_length                                # :521-522 (as the reference)
+
+        # ---- greedy skip decoding (:525-570) ----
+        L = self.args.max_length
+        with torch.no_grad():
+            oin = origin_input.detach()
+            cand_idx = torch.arange(S1 + 5, device=dev).unsqueeze(0).expand(batch_size, -1).contiguous()
+            cand_in = ops.lp_gather(oin, origin_length, cand_idx, eos_embed.detach(), unk_embed.detach(), None, 0, False)
+            KC = self.wk(cand_in)
+            kunk = self.wk(unk_embed.detach().view(1, d)).view(d)
+            unk_d = unk_embed.detach().contiguous()
+            now_pos = torch.zeros(batch_size, dtype=torch.long, device=dev)
+            allpos_buf = torch.zeros(batch_size, L + 1, dtype=torch.long, device=dev)
+            cache = KVCacheDecoder(self.decoder, oin, src_mask, L)
+            x = (oin[:, 0] + self.pos_embed.weight[0]).contiguous()           # step-0 input: cand_in[b,0] + pos[0]
+            x_next = torch.empty_like(x)
+            olen = origin_length.contiguous()
+            steps = 0
+            for k in range(L):
+                hid = cache.step(x, k)
+                qh = self.wq(hid)
+                ops.call("nast_lp_step_f32", qh.data_ptr(), hid.data_ptr(), KC.data_ptr(), kunk.data_ptr(),
+                         self.linear.weight.data_ptr(), self.linear.bias.data_ptr(), cand_in.data_ptr(), unk_d.data_ptr(),
+                         self.pos_embed.weight.data_ptr(), olen.data_ptr(), now_pos.data_ptr(), allpos_buf.data_ptr(),
+                         x_next.data_ptr(), batch_size, S1, d, k, L + 1, 1 if k + 1 < L else 0, ops._stream())
+                x, x_next = x_next, x
+                steps = k + 1
+                if k % 5 == 0 and (now_pos >= (origin_length + 1)).sum().tolist() == batch_size:     # :569
+                    break
+            allpos = allpos_buf[:, :steps + 1].contiguous()
+        dec_input = ops.lp_gather(origin_input, origin_length, allpos, eos_embed, unk_embed, None, 0, True)   # :576-578
+        target_length = (allpos < (origin_length + 1).unsqueeze(-1)).sum(dim=1) - 1                  # :580
+        return dec_input[:, :target_length.max() + 1], target_length, allpos

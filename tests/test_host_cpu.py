@@ -1,0 +1,201 @@
+"""CPU: host-side logic of the product (no kernel launches): C-ABI exports, state_dict contract,
+parameter groups, noise layer, batch preprocessing, and the data-parallel reducer on gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, sub
+from helpers import make_param, cfg_of, load_weights, FakeDM
+
+
+def test_cabi_exports_every_declared_symbol():
+    from nast_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "nast_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nast_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)        # loads without a GPU; no compute call is made here
+    for name in declared:
+        assert hasattr(lib, name), name
+    for name in declared:                   # argument counts of the binding follow the header
+        m = re.search(name + r"\s*\(([^;]*?)\)\s*;", hdr, re.S)
+        args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        assert len(args) == len(_lib.SIGNATURES[name]), name
+    assert _lib.load().nast_version() >= 100
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from nast_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libnast_hip.so")
+    with pytest.raises(_lib.NastHipError):
+        _lib.load()
+
+
+def test_cpu_tensor_is_rejected_not_emulated():
+    from nast_amd import ops, _lib
+    with pytest.raises(_lib.NastHipError):
+        ops.linear(torch.zeros(2, 4), torch.zeros(3, 4), torch.zeros(3))
+
+
+@pytest.mark.parametrize("tag", ["simple", "learnable"])
+def test_state_dict_contract(tag):
+    """Key names + shapes equal the reference's (captured in the golden files), incl. noiseLayer.cnt."""
+    from nast_amd.transformer import Network
+    g = load_golden(f"g9_{tag}_f_step")
+    net = Network(make_param(**cfg_of(g)))
+    gold = sub(g, "w0/")
+    own = net.state_dict()
+    assert set(own) == set(gold), set(own) ^ set(gold)
+    for k, v in gold.items():
+        assert tuple(own[k].shape) == tuple(v.shape), k
+    f_names = {n for n, _ in net.named_parameters() if n.startswith("model_F.")}
+    d_names = {n for n, _ in net.named_parameters() if n.startswith("model_D.")}
+    name_of = {id(p): n for n, p in net.named_parameters()}
+    assert {name_of[id(p)] for p in net.get_parameters_by_name("F", silent=True)} == f_names
+    assert {name_of[id(p)] for p in net.get_parameters_by_name("D", silent=True)} == d_names
+
+
+def test_embedding_init_quirk():
+    """All embeddings start at exactly 0 except length_predictor.pos_embed (only row 0 zero): SURVEY section 0."""
+    from nast_amd.transformer import Network
+    net = Network(make_param(V=40, d=32, h=4, N=1, L=8, learnable=True))
+    F = net.model_F
+    assert F.embed.token_embed.weight.abs().max() == 0 and F.style_embed.weight.abs().max() == 0
+    assert F.length_predictor.pos_embed.weight[0].abs().max() == 0
+    assert F.length_predictor.pos_embed.weight[1:].abs().max() > 0
+
+
+def test_noise_layer_matches_reference_draws():
+    """With the numpy seed the golden run used, word_blank reproduces the reference's noisy batch exactly."""
+    from nast_amd.noise import NoiseLayer
+    g = load_golden("g9_simple_f_step")
+    nl = NoiseLayer(0.2, 0, 0, 0, 0, keep_go=False, max_length=8, dm=FakeDM(40, 8))
+    np.testing.assert_allclose(nl.cnt.numpy(), g["w0/noiseLayer.cnt"], rtol=1e-6)
+    np.random.seed(19)
+    for s in ("s0/", "s1/"):
+        sent, sl = torch.from_numpy(g[s + "in/sent"]), torch.from_numpy(g[s + "in/sent_length"])
+        w, l = nl(sent.t(), sl, 1 - torch.from_numpy(g[s + "in/domain"]))
+        assert np.array_equal(w.t().numpy(), g[s + "in/noise_tok"]) and np.array_equal(l.numpy(), g[s + "in/noise_len"])
+
+
+def test_noise_layer_learnable_invariants():
+    from nast_amd.noise import NoiseLayer
+    L, V, B = 16, 60, 64
+    nl = NoiseLayer(0.1, 0.05, 0, 0, 1 / 0.95 - 1, keep_go=False, max_length=L, dm=FakeDM(V, L))
+    rng = np.random.default_rng(1)
+    from helpers import synth_batch
+    np.random.seed(3); torch.manual_seed(3)
+    for _ in range(20):
+        sent, sl = synth_batch(rng, B, L, V)
+        w, l = nl(sent.t(), sl, torch.randint(0, 2, (B,)))
+        w, l = w.t().numpy(), l.numpy()
+        assert w.shape[1] == l.max() <= L and l.min() >= 1
+        for b in range(B):
+            assert (w[b, l[b]:] == 0).all()                      # padded with <pad>
+            assert w[b, l[b] - 1] == 2 or l[b] == L              # ends with <eos> unless truncated at max_length
+            assert (w[b, :l[b]] != 0).all() and (w[b, :l[b]] != 1).all()
+
+
+def test_noise_stages_known_answers():
+    from nast_amd.noise import NoiseLayer
+    nl = NoiseLayer(0.5, 0.5, 0, 0, 0.5, keep_go=False, max_length=6, dm=FakeDM(40, 6))
+    x = np.array([[10, 11, 12, 2, 0, 0]]).T
+    l = np.array([4])
+    u = np.array([[0.1, 0.9, 0.1, 0.1, 0.1, 0.1]]).T
+    assert nl.blank_apply(x, l, u)[0][:, 0].tolist() == [3, 11, 3, 2, 0, 0]       # eos and padding never blanked
+    # add: slots 1 and 3 hold inserted words
+    ua = np.array([[0.1, 0.9, 0.1, 0.9, 0.9]]).T
+    new = np.arange(30, 36)[:, None]
+    out, ln = nl.add_apply(x, l, ua, new)
+    assert out[:, 0].tolist() == [10, 31, 11, 33, 12, 2] and ln.tolist() == [6]
+    # dropout: drop the middle word
+    uk = np.array([[0.9, 0.1, 0.9, 0.9, 0.9, 0.9]]).T
+    out, ln = nl.dropout_apply(x, l, uk, np.ones((5, 1)), lambda n: 0)
+    assert out[:, 0].tolist() == [10, 12, 2] and ln.tolist() == [3]
+    # everything dropped -> one picked word survives
+    out, ln = nl.dropout_apply(x, l, np.zeros((6, 1)), np.ones((5, 1)), lambda n: 1)
+    assert out[:, 0].tolist() == [11, 2]
+
+
+def test_preprocess_batch_and_temperature():
+    from nast_amd.seq2seq import Seq2seq
+    s = Seq2seq.__new__(Seq2seq)
+    d0 = {"sent": np.array([[1, 5, 6, 2], [1, 7, 2, 0]]), "sent_length": [4, 3]}
+    d1 = {"sent": np.array([[1, 8, 9, 10, 2]]), "sent_length": [5]}
+    from nast_amd.utils import cuda_init
+    cuda_init(0, "cpu")
+    inc = s._preprocess_batch(d0, d1)
+    assert inc.data.sent.tolist() == [[5, 6, 2, 0], [7, 2, 0, 0], [8, 9, 10, 2]]
+    assert inc.data.sent_length.tolist() == [3, 2, 4] and inc.data.domain.tolist() == [0, 0, 1]
+    assert s.calc_temperature([(1, 0)], 7) == 1
+    assert abs(s.calc_temperature([(1.0, 0), (0.5, 10)], 5) - 0.75) < 1e-12
+
+
+def test_utils_surface():
+    import nast_amd.utils as U
+    g = load_golden("g10_misc")
+    U.cuda_init(0, "cpu")
+    np.testing.assert_array_equal(U.generateMask(5, g["generateMask/len"], type=float).numpy(), g["generateMask/out"])
+    st = U.Storage(a=1)
+    st.b = U.Storage(c=2)
+    assert st.a == 1 and st.b.c == 2 and "a" in st
+    with pytest.raises(AttributeError):
+        st.zzz
+    assert U.onehot(torch.tensor([[1, 0]]), 3).tolist() == [[[0, 1, 0], [1, 0, 0]]]
+    for name in ("gumbel_max", "gumbel_max_with_mask", "gumbel_softmax", "straight_max", "onehot", "cdist",
+                 "recenter_gradient", "RebarGradient", "generateMask", "Storage", "BaseNetwork", "cuda_init"):
+        assert hasattr(U, name)
+
+
+DDP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from nast_amd.ddp import GradReducer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 4))
+unused = torch.nn.Parameter(torch.zeros(3))                      # like sos_token: never gets a gradient
+params = list(net.parameters()) + [unused]
+red = GradReducer(params, bucket_bytes=4096)
+ref = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 4))
+ref.load_state_dict(net.state_dict())
+g = torch.Generator().manual_seed(5)
+for step in range(3):
+    X = torch.randn(2 * world * 4, 16, generator=g); Y = torch.randn(2 * world * 4, 4, generator=g)
+    Xa, Ya = X[: world * 4], Y[: world * 4]; Xb, Yb = X[world * 4:], Y[world * 4:]
+    sl = slice(rank * 4, rank * 4 + 4)
+    for p in params: p.grad = None
+    # two backward passes accumulating into the same grads; only the second is reduced (f_step pattern)
+    ((net(Xa[sl]) - Ya[sl]) ** 2).sum().div(4).backward()
+    red.arm()
+    ((net(Xb[sl]) - Yb[sl]) ** 2).sum().div(4).backward()
+    red.finish()
+    for p in ref.parameters(): p.grad = None
+    (((ref(Xa) - Ya) ** 2).sum() / (4 * world) + ((ref(Xb) - Yb) ** 2).sum() / (4 * world)).backward()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), (step, (p.grad - q.grad).abs().max())
+    assert unused.grad is None
+    assert len(red.plan) > 1
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_grad_reducer_gloo_world2(tmp_path):
+    """N-rank averaged gradients == single-process gradients on the concatenated batch."""
+    script = tmp_path / "w.py"
+    script.write_text(DDP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

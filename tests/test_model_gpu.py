@@ -1,0 +1,255 @@
+"""GPU: the product modules (HIP kernels behind the reference's nn.Module API) against fixtures captured
+from the unmodified reference.  fp32 tolerance 1e-4 relative (north_star); alignment indices exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub
+from helpers import make_param, cfg_of, load_weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a)).to(DEV)
+
+
+def relclose(a, b, tol=1e-4, what=""):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    scale = np.abs(b).max() + 1e-30
+    assert err <= tol * scale + 1e-7, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def check_grads(module, gold, tol=2e-4, gscale=None):
+    """Every golden gradient must match; tolerance relative to the largest gradient in the model
+    (per-tensor where the tensor's own scale is meaningful)."""
+    named = dict(module.named_parameters())
+    gscale = gscale or max(float(np.abs(v).max()) for v in gold.values())
+    n = 0
+    for k, gv in gold.items():
+        p = named[k]
+        assert p.grad is not None, k
+        err = float((p.grad.detach().cpu().double() - torch.from_numpy(gv).double()).abs().max())
+        scale = max(float(np.abs(gv).max()), 1e-3 * gscale)
+        assert err <= tol * scale, f"grad {k}: err {err:.3e} scale {scale:.3e}"
+        n += 1
+    for k, p in named.items():
+        if k not in gold:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{k} has a gradient the reference lacks"
+    assert n > 0
+
+
+def test_layers_golden():
+    from nast_amd import transformer as tf
+    g = load_golden("g1_layers")
+    x, mem = T(g["in/x"]).requires_grad_(True), T(g["in/mem"]).requires_grad_(True)
+    masks = {"self_pad": T(g["in/pad_self"]), "cross_pad": T(g["in/pad_mem"]), "self_causal": T(g["in/causal"])}
+    mha = tf.MultiHeadAttention(32, 4, 0).to(DEV)
+    load_weights(mha, sub(g, "w/mha/"))
+    for tag in ("self_pad", "cross_pad", "self_causal"):
+        kv = mem if tag == "cross_pad" else x
+        mha.zero_grad(); x.grad = None; mem.grad = None
+        y = mha(x, kv, kv, masks[tag])
+        (y * T(g[f"in/mha/{tag}/R"])).sum().backward()
+        relclose(y, g[f"out/mha/{tag}/y"], what=tag)
+        relclose(x.grad, g[f"g/mha/{tag}/x"], 2e-4, tag)
+        check_grads(mha, sub(g, f"g/mha/{tag}/w/"))
+    enc = tf.EncoderLayer(32, 4, 0).to(DEV)
+    load_weights(enc, sub(g, "w/enc/"))
+    x.grad = None
+    y = enc(x, masks["self_pad"])
+    (y * T(g["in/enc/R"])).sum().backward()
+    relclose(y, g["out/enc/y"]); relclose(x.grad, g["g/enc/x"], 2e-4)
+    check_grads(enc, sub(g, "g/enc/w/"))
+    dec = tf.DecoderLayer(32, 4, 0).to(DEV)
+    load_weights(dec, sub(g, "w/dec/"))
+    for tag, tm in (("pad", masks["self_pad"]), ("causal", masks["self_causal"])):
+        dec.zero_grad(); x.grad = None; mem.grad = None
+        y = dec(x, mem, masks["cross_pad"], tm)
+        (y * T(g[f"in/dec/{tag}/R"])).sum().backward()
+        relclose(y, g[f"out/dec/{tag}/y"]); relclose(x.grad, g[f"g/dec/{tag}/x"], 2e-4); relclose(mem.grad, g[f"g/dec/{tag}/mem"], 2e-4)
+        check_grads(dec, sub(g, f"g/dec/{tag}/w/"))
+    # the fine-grained public pieces compose to the same numbers as the fused sublayers
+    y2 = enc.sublayer[0](x, lambda z: enc.self_attn(z, z, z, masks["self_pad"]))
+    y2 = enc.sublayer[1](y2, enc.pw_ffn)
+    relclose(y2, g["out/enc/y"])
+    q = torch.randn(3, 4, 7, 8, device=DEV)
+    out, _ = tf.scaled_attention(q, q, q, masks["self_pad"])
+    ref = torch.softmax((q @ q.transpose(-1, -2) / 8 ** 0.5).masked_fill(masks["self_pad"], float("-inf")), -1) @ q
+    relclose(out, ref.cpu().numpy())
+
+
+@pytest.mark.parametrize("tag", ["simple", "learnable"])
+def test_style_transformer_golden(tag):
+    from nast_amd import transformer as tf
+    g = load_golden(f"g2_style_transformer_{tag}")
+    F = tf.StyleTransformer(make_param(**cfg_of(g))).to(DEV)
+    assert not load_weights(F, sub(g, "w/"))
+    learnable = bool(g["cfg/learnable"])
+    src, sl, gold, gl, style = (T(g[k]) for k in ("in/src", "in/src_len", "in/gold", "in/gold_len", "in/style"))
+
+    F.zero_grad()
+    lp, tl, ll, ge, _ = F(src, sl, gold, gl, style, generate=False, temperature=1.0, use_inference_z=True)
+    relclose(lp, g["out/teacher_hard/log_probs"], what="teacher_hard")
+    loss = (lp * T(g["in/teacher_hard/R"])).sum()
+    if learnable:
+        with torch.no_grad():
+            ap = F.length_predictor.match(src, sl, gold, gl, F.embed)
+        assert np.array_equal(ap.cpu().numpy(), g["out/teacher_hard/allpos"])
+        relclose(ll, g["out/teacher_hard/length_loss"]); relclose(ge, g["out/teacher_hard/gen_err"])
+        assert np.array_equal(tl.cpu().numpy(), g["out/teacher_hard/tgt_lengths"])
+        loss = loss + (ll * T(g["in/teacher_hard/W"])).sum()
+    loss.backward()
+    check_grads(F, sub(g, "g/teacher_hard/"))
+    with torch.no_grad():
+        relclose(F(src, sl, gold, gl, style, generate=False, temperature=0.7, use_inference_z=True)[0],
+                 g["out/teacher_hard_t07/log_probs"], what="t07")
+
+    F.zero_grad()
+    soft = T(g["in/teacher_soft/soft"]).requires_grad_(True)
+    lp, tl, ll, ge, _ = F(soft, sl, gold, gl, style, generate=False, temperature=1.0, use_inference_z=True)
+    relclose(lp, g["out/teacher_soft/log_probs"], what="teacher_soft")
+    loss = (lp * T(g["in/teacher_soft/R"])).sum()
+    if learnable:
+        with torch.no_grad():
+            ap = F.length_predictor.match(soft.detach(), sl, gold, gl, F.embed)
+        assert np.array_equal(ap.cpu().numpy(), g["out/teacher_soft/allpos"])
+        relclose(ll, g["out/teacher_soft/length_loss"])
+        loss = loss + (ll * T(g["in/teacher_soft/W"])).sum()
+    loss.backward()
+    relclose(soft.grad, g["gx/teacher_soft/soft"], 2e-4)
+    check_grads(F, sub(g, "g/teacher_soft/"))
+
+    F.zero_grad()
+    lp, tl, _, _, ap = F(gold, gl, None, None, 1 - style, generate=True, temperature=1.0, use_inference_z=True)
+    if learnable:
+        assert np.array_equal(ap.cpu().numpy(), g["out/generate/allpos"])
+        assert np.array_equal(tl.cpu().numpy(), g["out/generate/tgt_lengths"])
+    relclose(lp, g["out/generate/log_probs"], what="generate")
+    (lp * T(g["in/generate/R"])).sum().backward()
+    check_grads(F, sub(g, "g/generate/"))
+
+    if learnable:
+        with torch.no_grad():
+            out = F(gold, gl, gold, gl, style, generate=False, temperature=1.0, use_inference_z=False)
+            relclose(out[0], g["out/teacher_noz/log_probs"], what="noz")
+            hd = F.length_predictor.decoder
+            x, mem, sm = T(g["in/hd/x"]), T(g["in/hd/mem"]), T(g["in/hd/smask"])
+            n = x.shape[1]
+            causal = (torch.ones(n, n, device=DEV).tril() == 0).view(1, 1, n, n)
+            relclose(hd(x, mem, sm, causal), g["out/hd/forward"], what="hd.forward")
+            st, ys = None, []
+            for k in range(n):
+                yk, st = hd.incremental_forward(x[:, k:k + 1], mem, sm, causal[:, :, k:k + 1, :k + 1], st)
+                ys.append(yk)
+            relclose(torch.cat(ys, 1), g["out/hd/incremental"], what="hd.incremental")
+            cache = tf.KVCacheDecoder(hd, mem, sm, n)
+            relclose(torch.stack([cache.step(x[:, k].contiguous(), k) for k in range(n)], 1), g["out/hd/incremental"], what="kv-cache")
+
+
+@pytest.mark.parametrize("disc", ["cond", "multi"])
+def test_discriminator_golden(disc):
+    from nast_amd import transformer as tf
+    g = load_golden(f"g8_discriminator_{disc}")
+    D = tf.Discriminator(make_param(learnable=False, **cfg_of(g))).to(DEV)
+    assert not load_weights(D, sub(g, "w/"))
+    tok, tl = T(g["in/tok"]), T(g["in/len"])
+    style = T(g["in/style"]) if "in/style" in g else None
+    lp = D(tok, tl, style)
+    relclose(lp, g["out/hard/log_probs"])
+    (lp * T(g["in/hard/R"])).sum().backward()
+    check_grads(D, sub(g, "g/hard/"))
+    D.zero_grad()
+    soft = T(g["in/soft/soft"]).requires_grad_(True)
+    lp = D(soft, tl, style)
+    relclose(lp, g["out/soft/log_probs"])
+    (lp * T(g["in/soft/R"])).sum().backward()
+    relclose(soft.grad, g["gx/soft/soft"], 2e-4)
+    check_grads(D, sub(g, "g/soft/"))
+
+
+def test_gumbel_api_golden():
+    import nast_amd.utils as U
+    g = load_golden("g7_gumbel")
+    logits = T(g["in/logits"])
+    for name in ("gumbel_max", "gumbel_max_tau"):
+        x = logits.clone().requires_grad_(True)
+        with U.inject_noise([T(g[f"in/{name}/E"])]):
+            ret, ys = U.gumbel_max(x, tau=float(g[f"in/{name}/tau"]))
+        relclose(ys, g[f"out/{name}/y_soft"]); relclose(ret, g[f"out/{name}/ret"])
+        (ret * T(g[f"in/{name}/R_ret"])).sum().backward(retain_graph=True)
+        relclose(x.grad, g[f"g/{name}/from_ret"], 2e-4)
+        x.grad = None
+        (ys * T(g[f"in/{name}/R_soft"])).sum().backward()
+        relclose(x.grad, g[f"g/{name}/from_soft"], 2e-4)
+    x = logits.clone().requires_grad_(True)
+    with U.inject_noise([T(g["in/gumbel_softmax/E"])]):
+        y = U.gumbel_softmax(x, tau=0.8)
+    relclose(y, g["out/gumbel_softmax/y"])
+    (y * T(g["in/gumbel_softmax/R"])).sum().backward()
+    relclose(x.grad, g["g/gumbel_softmax/x"], 2e-4)
+    x = logits.clone().requires_grad_(True)
+    with U.inject_noise([T(g["in/gumbel_max_with_mask/E"])]):
+        y = U.gumbel_max_with_mask(x, T(g["in/gumbel_max_with_mask/mask"]))
+    relclose(y, g["out/gumbel_max_with_mask/y"])
+    (y * T(g["in/gumbel_max_with_mask/R"])).sum().backward()
+    relclose(x.grad, g["g/gumbel_max_with_mask/x"], 2e-4)
+    for allow in (0, 1):
+        x = logits.clone().requires_grad_(True)
+        yh, ys = U.straight_max(x, allow_gradient=bool(allow))
+        relclose(yh, g[f"out/straight_max_{allow}/y_hard"]); relclose(ys, g[f"out/straight_max_{allow}/y_soft"])
+        if allow:
+            (yh * T(g["in/straight_max_1/R"])).sum().backward()
+            relclose(x.grad, g["g/straight_max_grad/x"], 2e-4)
+
+
+@pytest.mark.parametrize("tag", ["simple", "learnable"])
+@pytest.mark.parametrize("mode", ["f_step", "d_step", "f_step_pretrain"])
+def test_training_steps_golden(tag, mode):
+    """Two consecutive steps from the captured weights / batch / noisy batch / Gumbel draws: returned losses,
+    pre-clip gradient norm, clipped gradients and post-Adam weights (seq2seq.py:416-543, :551-642)."""
+    import nast_amd.utils as U
+    from nast_amd.seq2seq import Seq2seq
+    from nast_amd.utils import Storage
+    g = load_golden(f"g9_{tag}_{mode}")
+    U.cuda_init(0, "cuda")
+    model = Seq2seq(make_param(device="cuda", **cfg_of(g)))
+    assert not load_weights(model.net, sub(g, "w0/"))
+    model.net.model_F.train(); model.net.model_D.train()
+    pref = "model_D." if mode == "d_step" else "model_F."
+    for step in range(2):
+        s = f"s{step}/"
+        inc = Storage(); inc.data = Storage()
+        inc.data.sent, inc.data.sent_length, inc.data.domain = T(g[s + "in/sent"]), T(g[s + "in/sent_length"]), T(g[s + "in/domain"])
+        E = [T(g[s + f"in/E{i}"]) for i in range(int(g[s + "in/nE"]))]
+        if mode != "d_step":
+            nt, nl = T(g[s + "in/noise_tok"]), T(g[s + "in/noise_len"])
+            model.net.noiseLayer.forward = lambda w, l, rev_domain, nt=nt, nl=nl: (nt.t(), nl)
+        with U.inject_noise(E):
+            if mode == "d_step":
+                ret = (model.d_step(inc, 1.0, use_inference_z=True),)
+            else:
+                ret = model.f_step(inc, 1.0, cyc_rec_enable=(mode == "f_step"), use_inference_z=True)
+        np.testing.assert_allclose(np.asarray(ret, dtype=np.float64), g[s + "out/ret"], rtol=2e-4, atol=1e-5)
+        if float(g[s + "out/grad_norm"]) >= 0:
+            np.testing.assert_allclose(float(model.last_grad_norm), float(g[s + "out/grad_norm"]), rtol=2e-4)
+        gold_g = sub(g, s + "g/")
+        gscale = max(float(np.abs(v).max()) for v in gold_g.values())
+        named = dict(model.net.named_parameters())
+        for k, v in sub(g, s + "w/").items():
+            if not k.startswith(pref) or k not in named:
+                continue
+            short = k[len(pref):]
+            w = named[k].detach().cpu().numpy()
+            if short in gold_g:
+                gg = gold_g[short]
+                np.testing.assert_allclose(named[k].grad.cpu().numpy(), gg, rtol=1e-3, atol=1e-5 * gscale, err_msg=k)
+                solid = np.abs(gg) > 1e-3 * gscale     # Adam's first steps are ill-conditioned where |g| ~ rounding noise
+                np.testing.assert_allclose(w[solid], v[solid], rtol=1e-4, atol=1e-5, err_msg=k)
+                np.testing.assert_allclose(w, v, rtol=0, atol=2.5e-4, err_msg=k)
+            else:
+                np.testing.assert_allclose(w, v, rtol=1e-6, atol=1e-7, err_msg=k)
