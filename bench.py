@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train sentences/sec of the NAST-StyTrans (learnable alignment) generator training step.
+
+A "step" is one `Seq2seq.f_step` as the reference defines it (seq2seq.py:416-543): host NoiseLayer, three
+generator forward passes (self-reconstruction, transfer with greedy skip decoding, cycle reconstruction from
+Gumbel-softmax soft tokens), one discriminator forward, two backward passes, global-norm clip and Adam.
+
+Workload (BASELINE.json configs[2]): learnable alignment, GYAFC-shaped synthetic batch (len <= 32, vocab 9600,
+d=256, h=4, 4 layers), 64 sentences per GPU, fp32 (the reference's dtype), use_inference_z=True.
+Weak scaling: every rank holds its own 64 sentences; gradients are averaged with bucketed RCCL all-reduce.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md section "Measurement").
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# algorithmic GFLOP per sentence of one f_step (SURVEY.md section 8d / BASELINE.md section 3)
+GFLOP_PER_SENTENCE = {("learnable", 32): 10.1, ("learnable", 16): 5.12, ("simple", 16): 3.80}
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
+
+
+def synth_incoming(B, L, V, seed, device):
+    """tokens ~ U{4..V-1}, lengths (incl. eos) ~ U{4..L}, sentence 0 has length L,
+    first half style 0, second half style 1."""
+    from nast_amd.utils import Storage
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(4, L + 1, size=B)
+    lens[0] = L
+    sent = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        n = int(lens[b])
+        sent[b, :n - 1] = rng.integers(4, V, size=n - 1)
+        sent[b, n - 1] = 2
+    inc = Storage(); inc.data = Storage()
+    inc.data.sent = torch.from_numpy(sent).to(device)
+    inc.data.sent_length = torch.from_numpy(lens.astype(np.int64)).to(device)
+    inc.data.domain = torch.tensor([0] * (B // 2) + [1] * (B - B // 2), device=device)
+    inc.data.batch_size = B
+    return inc
+
+
+def build_model(cfg, device):
+    from helpers import make_param
+    import nast_amd.utils as U
+    from nast_amd.seq2seq import Seq2seq
+    torch.manual_seed(0)
+    np.random.seed(0)
+    U.cuda_init(torch.cuda.current_device() if device == "cuda" else 0, device)
+    model = Seq2seq(make_param(device=device, **cfg))
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in model.net.named_parameters():
+            # reference init leaves every embedding at exactly 0 (degenerate alignment): re-draw xavier-uniform
+            if n.endswith("embed.weight"):
+                bound = (6.0 / (p.shape[0] + p.shape[1])) ** 0.5
+                p.copy_(((torch.rand(p.shape, generator=gen) * 2 - 1) * bound).to(p.device))
+        cnt = model.net.noiseLayer.cnt
+        cnt.zero_()
+        cnt[:, 4:] = 1.0 / (cnt.shape[1] - 4)
+    model.net.model_F.train(); model.net.model_D.train()
+    model.net.model_F.check_lengths = False        # the reference's host-side assert (a D2H sync per forward)
+    return model
+
+
+def cpu_baseline(model, cfg, B, steps=2):
+    """The CPU oracle (oracle/nast_oracle.py, pinned against the reference by the golden fixtures) timed on this
+    box's host cores on a bounded sample of the same workload."""
+    from oracle import nast_oracle as O
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    weights = {k: v.detach().cpu().clone() for k, v in model.net.state_dict().items() if k.startswith("model_")}
+    tr = O.Trainer(weights, O.Cfg(**cfg))
+    inc = synth_incoming(B, cfg["L"], cfg["V"], 1234, "cpu")
+    sent, slen, dom = inc.data.sent, inc.data.sent_length, inc.data.domain
+    times = []
+    for i in range(steps + 1):
+        np.random.seed(i)
+        ntok, nlen = model.net.noiseLayer(sent.t(), slen, 1 - dom)
+        ntok = ntok.t().contiguous().cpu(); nlen = nlen.cpu()
+        t0 = time.perf_counter()
+        if cfg["learnable"]:
+            with torch.no_grad():
+                glp = O.style_transformer(tr.w, tr.cfg, sent, slen, None, None, 1 - dom, True, 1.0, True)[0]
+            E = torch.empty_like(glp).exponential_()
+        else:
+            E = torch.empty(B, cfg["L"], cfg["V"]).exponential_()
+        t1 = time.perf_counter()
+        tr.f_step(sent, slen, dom, ntok, nlen, [E])
+        t2 = time.perf_counter()
+        if i > 0:
+            times.append(t2 - t1)      # the shape probe (t1 - t0) is harness overhead, not part of the step
+    sps = B / (sum(times) / len(times))
+    return {"value": round(sps, 2), "unit": "sentences/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} f_step of the same workload (B={B}) after 1 warm-up, torch CPU fp32, {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--alignment", default="learnable", choices=["learnable", "simple"])
+    ap.add_argument("--max-length", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    learnable = a.alignment == "learnable"
+    L = a.max_length or (32 if learnable else 16)
+    cfg = dict(V=9600, d=256, h=4, N=4, L=L, learnable=learnable)
+    B = a.batch_per_gpu
+    model = build_model(cfg, "cuda")
+    # every rank holds different sentences (its shard of the global batch) and identical weights
+    batches = [synth_incoming(B, L, cfg["V"], 1000 * rank + i, "cuda") for i in range(4)]
+    np.random.seed(100 + rank)
+    torch.cuda.manual_seed(100 + rank)
+
+    def run(n, offset=0):
+        for i in range(n):
+            model.f_step(batches[(i + offset) % len(batches)], 1.0, use_inference_z=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(a.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run(a.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roofline = None
+    if rank == 0 and not a.no_roofline:
+        # second pass over the same steps with HIP-event timing armed around every launch of the dominant
+        # kernel family (grouped fp32 MFMA GEMM); kept out of the pass that produces `value`
+        from nast_amd import _lib
+        lib = _lib.load()
+        lib.nast_prof_begin(1)
+        run(min(a.steps, 5), offset=a.warmup)
+        torch.cuda.synchronize()
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        lib.nast_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        if ms.value > 0:
+            ach = fl.value / (ms.value * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "nast_gemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
+                        "avg_launch_gflop": round(fl.value / max(n.value, 1) / 1e9, 4)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        sps = B * world * a.steps / elapsed
+        key = ("learnable" if learnable else "simple", L)
+        out = {
+            "metric": "train sentences/sec (fwd+bwd, NAST-StyTrans learnable)" if learnable else "train sentences/sec (fwd+bwd, NAST-StyTrans simple)",
+            "value": round(sps, 2), "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"NAST-StyTrans f_step, {a.alignment} alignment, len<={L}, vocab 9600, d=256, h=4, 4 layers, "
+                                   f"{B} sentences/GPU (BASELINE configs[{2 if learnable else 1}])",
+                       "global_batch": B * world, "max_length": L, "parallelism": f"dp{world}"},
+        }
+        if key in GFLOP_PER_SENTENCE:
+            tf = sps * GFLOP_PER_SENTENCE[key] / 1e3
+            out["step_tflops"] = round(tf, 2)
+            out["step_frac_of_fp32_mfma_peak"] = round(tf / (PEAK_FP32_MFMA_TFLOPS * world), 4)
+        if roofline:
+            out["roofline"] = roofline
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model, cfg, B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

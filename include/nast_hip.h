@@ -51,6 +51,9 @@ typedef struct nast_gemm_desc {
   const float* residual;             /* [M, ldc] or NULL, added after bias                                     */
   const float* relu_src;             /* [M, ldc] or NULL: C = relu_src > 0 ? C : 0 (ReLU backward)             */
   float* colsum;                     /* [M] or NULL: with transA=1, colsum[m] (+)= sum_k op(A[0])[m,k]  (bias grad) */
+  const float* ln_gamma;             /* [K] or NULL: op(A) rows are LayerNorm-ed on the fly (eps 1e-6) before the   */
+  const float* ln_beta;              /* product (pre-LN sublayers, transformer.py:324-330). Small-M path only:      */
+                                     /* needs M <= 128, K <= 256, transA=0, transB=1, else NAST_EINVAL.             */
   int32_t M, N, K;
   int32_t lda, ldb, ldc;
   int32_t transA, transB;
@@ -200,11 +203,42 @@ int nast_lp_gather_bwd_f32(const float* dout, const int64_t* origin_length, cons
  *   delta = first argmax; now = min(now + delta, S1); allpos[b, step+1] = now;
  *   x_next[b] = (delta == 0 ? unk : cand_in[b, now]) + pos_w[step+1]      (next decoder input, :535-540)
  * qh = wq(hidden), hid = hidden [B,d]; KC = wk(cand_in) [B,S1+5,d]; kunk = wk(unk) [d]; cand_in [B,S1+5,d];
- * lin_w [4,d], lin_b [4]; now_pos int64 [B] (in/out); allpos int64 [B, ldp].                          */
+ * lin_w [4,d], lin_b [4]; now_pos int64 [B] (in/out); allpos int64 [B, ldp].
+ * norm_w/norm_b (may be NULL): when given, `hid` is the un-normalised decoder output and the final
+ * LayerNorm of HiddenDecoder.incremental_forward (transformer.py:376) is applied inside the kernel.    */
 int nast_lp_step_f32(const float* qh, const float* hid, const float* KC, const float* kunk,
                      const float* lin_w, const float* lin_b, const float* cand_in, const float* unk,
                      const float* pos_w, const int64_t* origin_length, int64_t* now_pos, int64_t* allpos,
-                     float* x_next, int B, int S1, int d, int step, int ldp, int write_next, void* stream);
+                     float* x_next, const float* norm_w, const float* norm_b,
+                     int B, int S1, int d, int step, int ldp, int write_next, void* stream);
+
+/* Whole greedy skip-decoding loop of LengthPredictor.forward (generate branch, transformer.py:525-570) run from
+ * native code: candidate table, wk(candidates), cross-attention K/V of all layers, then per step and layer
+ * [LN+QKV GEMM] -> attention over the K/V cache -> [out GEMM + residual] -> [LN+q GEMM] -> cross attention ->
+ * [out GEMM] -> [LN+FFN1] -> FFN2, the skip decision kernel, and the reference's early exit (every 5th step,
+ * :569 -- this is the one place the library synchronises the stream: it copies a "finished" count to the host).
+ * All pointers in the structs are device pointers; *steps_out (host) receives the number of executed steps.   */
+typedef struct nast_declayer_weights {
+  const float *ln0_w, *ln0_b, *sa_wq, *sa_bq, *sa_wk, *sa_bk, *sa_wv, *sa_bv, *sa_wo, *sa_bo;
+  const float *ln1_w, *ln1_b, *ca_wq, *ca_bq, *ca_wk, *ca_bk, *ca_wv, *ca_bv, *ca_wo, *ca_bo;
+  const float *ln2_w, *ln2_b, *ff_w1, *ff_b1, *ff_w2, *ff_b2;
+} nast_declayer_weights;
+
+typedef struct nast_lp_decode_args {
+  int32_t B, S1, d, h, dff, L, nlayers;
+  const nast_declayer_weights* layers;   /* HOST array of nlayers entries */
+  const float *norm_w, *norm_b;          /* HiddenDecoder.norm */
+  const float *wq_w, *wq_b, *wk_w, *wk_b, *lin_w, *lin_b;
+  const float* pos_w;                    /* length_predictor.pos_embed.weight [L+1,d] */
+  const float *eos, *unk;                /* token_embed rows [d] */
+  const float* memory;                   /* origin_input [B,S1,d] (encoder memory, style token first) */
+  const int64_t* origin_length;          /* [B] */
+  int64_t* allpos;                       /* [B, L+1] out; column 0 = 0 */
+  float* workspace;                      /* nast_lp_decode_workspace_bytes() bytes, 256-B aligned */
+} nast_lp_decode_args;
+
+int64_t nast_lp_decode_workspace_bytes(int B, int S1, int d, int dff, int L, int nlayers);
+int nast_lp_decode_f32(const nast_lp_decode_args* args, int* steps_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser side (seq2seq.py:536-537, :637-638): multi-tensor L2 norm + clip + Adam in few launches.

@@ -18,11 +18,27 @@ c_fp = C.c_void_p   # all device pointers travel as void*
 
 class GemmDesc(C.Structure):
     _fields_ = [("A", c_fp * GEMM_MAX_SRC), ("B", c_fp * GEMM_MAX_SRC), ("C", c_fp), ("bias", c_fp),
-                ("residual", c_fp), ("relu_src", c_fp), ("colsum", c_fp),
+                ("residual", c_fp), ("relu_src", c_fp), ("colsum", c_fp), ("ln_gamma", c_fp), ("ln_beta", c_fp),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
                 ("transA", C.c_int32), ("transB", C.c_int32), ("nsrc", C.c_int32), ("flags", C.c_int32),
                 ("alpha", C.c_float)]
+
+
+_DECLAYER_FIELDS = ["ln0_w", "ln0_b", "sa_wq", "sa_bq", "sa_wk", "sa_bk", "sa_wv", "sa_bv", "sa_wo", "sa_bo",
+                    "ln1_w", "ln1_b", "ca_wq", "ca_bq", "ca_wk", "ca_bk", "ca_wv", "ca_bv", "ca_wo", "ca_bo",
+                    "ln2_w", "ln2_b", "ff_w1", "ff_b1", "ff_w2", "ff_b2"]
+
+
+class DecLayerWeights(C.Structure):
+    _fields_ = [(n, c_fp) for n in _DECLAYER_FIELDS]
+
+
+class LPDecodeArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "S1", "d", "h", "dff", "L", "nlayers")] + \
+               [("layers", C.POINTER(DecLayerWeights))] + \
+               [(n, c_fp) for n in ("norm_w", "norm_b", "wq_w", "wq_b", "wk_w", "wk_b", "lin_w", "lin_b", "pos_w", "eos", "unk",
+                                    "memory", "origin_length", "allpos", "workspace")]
 
 
 class Rows(C.Structure):
@@ -53,13 +69,15 @@ SIGNATURES = {
     "nast_align_lse_bwd_f32": [c_fp] * 4 + [_f] + [c_fp] * 5 + [_i, _i, _i, c_fp],
     "nast_lp_gather_fwd_f32": [c_fp] * 7 + [_i] * 6 + [c_fp],
     "nast_lp_gather_bwd_f32": [c_fp] * 7 + [_i] * 7 + [c_fp],
-    "nast_lp_step_f32": [c_fp] * 13 + [_i] * 6 + [c_fp],
+    "nast_lp_step_f32": [c_fp] * 15 + [_i] * 6 + [c_fp],
+    "nast_lp_decode_workspace_bytes": [_i] * 6,
+    "nast_lp_decode_f32": [C.POINTER(LPDecodeArgs), C.POINTER(C.c_int), c_fp],
     "nast_multi_sqnorm_f32": [c_fp, c_fp, _i, c_fp, c_fp],
     "nast_multi_adam_f32": [c_fp] * 5 + [_i, c_fp] + [_f] * 8 + [c_fp],
     "nast_prof_begin": [_i],
     "nast_prof_end": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
 }
-_RESTYPES = {"nast_last_error": C.c_char_p}
+_RESTYPES = {"nast_last_error": C.c_char_p, "nast_lp_decode_workspace_bytes": C.c_int64}
 
 _lib = None
 

@@ -35,16 +35,16 @@ struct TileGeom {
   static constexpr int NV = R * BK / 1024;  // float4 chunks per thread (256 threads)
 };
 
-// global -> registers.  `rows` bounds the tile's row index, K bounds k.
-template <int R, int BK>
-__device__ __forceinline__ void tile_load(const float* __restrict__ src, int ld, bool kcontig, bool vec,
+// global -> registers.  `rows` bounds the tile's row index, K bounds k.  KC = k-contiguous source.
+template <int R, int BK, bool KC>
+__device__ __forceinline__ void tile_load(const float* __restrict__ src, int ld, bool vec,
                                           int row0, int rows, int k0, int K, float4 (&reg)[TileGeom<R, BK>::NV]) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int j = 0; j < TileGeom<R, BK>::NV; ++j) {
     const int c = tid + 256 * j;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kcontig) {
+    if (KC) {
       const int row = c / (BK / 4), kc = (c % (BK / 4)) * 4;
       const int gr = row0 + row, gk = k0 + kc;
       if (gr < rows && gk < K) {
@@ -77,15 +77,14 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ src, int ld,
   }
 }
 
-template <int R, int BK>
-__device__ __forceinline__ void tile_store(float* __restrict__ lds, bool kcontig,
-                                           const float4 (&reg)[TileGeom<R, BK>::NV]) {
+template <int R, int BK, bool KC>
+__device__ __forceinline__ void tile_store(float* __restrict__ lds, const float4 (&reg)[TileGeom<R, BK>::NV]) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int j = 0; j < TileGeom<R, BK>::NV; ++j) {
     const int c = tid + 256 * j;
     int off;
-    if (kcontig) {
+    if (KC) {
       const int row = c / (BK / 4), kc = (c % (BK / 4)) * 4;
       off = row * TileGeom<R, BK>::KC_LD + kc;
     } else {
@@ -97,9 +96,9 @@ __device__ __forceinline__ void tile_store(float* __restrict__ lds, bool kcontig
 }
 
 // fragment for one 32-row MFMA tile and one 8-wide k-group: 4 values = steps s = 0..3
-template <int R, int BK>
-__device__ __forceinline__ float4 frag_read(const float* __restrict__ lds, bool kcontig, int row, int g, int h) {
-  if (kcontig) {
+template <int R, int BK, bool KC>
+__device__ __forceinline__ float4 frag_read(const float* __restrict__ lds, int row, int g, int h) {
+  if (KC) {
     return *reinterpret_cast<const float4*>(lds + row * TileGeom<R, BK>::KC_LD + 8 * g + 4 * h);
   } else {
     const float* p = lds + (8 * g + 4 * h) * TileGeom<R, BK>::MC_LD + row;
@@ -107,32 +106,21 @@ __device__ __forceinline__ float4 frag_read(const float* __restrict__ lds, bool 
   }
 }
 
-template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) {
+// One output tile (and K slice) of one problem; operand layouts are compile-time so that the K loop is
+// branch-free: all fragment reads of a K-tile are issued first, then the MFMAs run back to back.
+template <int BM, int BN, int BK, bool AKC, bool BKC>
+__device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int tn, int kz, int kt_per_split, float* smem) {
   using GA = TileGeom<BM, BK>;
   using GB = TileGeom<BN, BK>;
-  constexpr int WTM = BM / 2, WTN = BN / 2, MT = WTM / 32, NT = WTN / 32;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (GA::SZ + GB::SZ)];
-
-  // ---- which problem / tile / k-slice ----
-  const int bid = blockIdx.x;
-  int gi = 0;
-  while (gi + 1 < P.count && bid >= P.tile_start[gi + 1]) ++gi;
-  const nast_gemm_desc& D = P.d[gi];
-  const int local = bid - P.tile_start[gi];
-  const int tn = local % P.tiles_n[gi];
-  const int tq = local / P.tiles_n[gi];
-  const int tm = tq % P.tiles_m[gi];
-  const int kz = tq / P.tiles_m[gi];
+  constexpr int WTM = BM / 2, WTN = BN / 2, MT = WTM / 32, NT = WTN / 32, NG = BK / 8;
   const int M = D.M, N = D.N, K = D.K;
   const int m0 = tm * BM, n0 = tn * BN;
-  const bool a_kc = (D.transA == 0), b_kc = (D.transB != 0);
   const int nkt = (K + BK - 1) / BK;
-  const int kt_lo = kz * P.kt_per_split[gi];
-  int kt_hi = kt_lo + P.kt_per_split[gi];
+  const int kt_lo = kz * kt_per_split;
+  int kt_hi = kt_lo + kt_per_split;
   if (kt_hi > nkt) kt_hi = nkt;
-  const int nsrc = D.nsrc;
-  const int steps = (kt_hi - kt_lo) * nsrc;
+  const int nk = kt_hi - kt_lo;
+  const int steps = nk * D.nsrc;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -147,24 +135,24 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   float colacc = 0.f;
-  const bool do_colsum = (D.colsum != nullptr) && (tn == 0) && !a_kc;
+  const bool do_colsum = !AKC && (D.colsum != nullptr) && (tn == 0);
+  const bool va = ((D.lda & 3) == 0) && (!AKC || (K & 3) == 0);
+  const bool vb = ((D.ldb & 3) == 0) && (!BKC || (K & 3) == 0);
 
   float4 ra[GA::NV], rb[GB::NV];
   auto issue = [&](int step) {
-    const int s = step / (kt_hi - kt_lo);
-    const int kt = kt_lo + step % (kt_hi - kt_lo);
+    const int s = step / nk;
+    const int kt = kt_lo + step - s * nk;
     const float* Ap = D.A[s];
     const float* Bp = D.B[s];
-    const bool va = ((D.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(Ap) & 15) == 0) && (a_kc ? (K & 3) == 0 : true);
-    const bool vb = ((D.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bp) & 15) == 0) && (b_kc ? (K & 3) == 0 : true);
-    tile_load<BM, BK>(Ap, D.lda, a_kc, va, m0, M, kt * BK, K, ra);
-    tile_load<BN, BK>(Bp, D.ldb, b_kc, vb, n0, N, kt * BK, K, rb);
+    tile_load<BM, BK, AKC>(Ap, D.lda, va && ((reinterpret_cast<uintptr_t>(Ap) & 15) == 0), m0, M, kt * BK, K, ra);
+    tile_load<BN, BK, BKC>(Bp, D.ldb, vb && ((reinterpret_cast<uintptr_t>(Bp) & 15) == 0), n0, N, kt * BK, K, rb);
   };
 
   if (steps > 0) {
     issue(0);
-    tile_store<BM, BK>(smem, a_kc, ra);
-    tile_store<BN, BK>(smem + GA::SZ, b_kc, rb);
+    tile_store<BM, BK, AKC>(smem, ra);
+    tile_store<BN, BK, BKC>(smem + GA::SZ, rb);
   }
   __syncthreads();
 
@@ -174,63 +162,248 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
     const float* Bs = As + GA::SZ;
     if (step + 1 < steps) issue(step + 1);
 
-    if (do_colsum && threadIdx.x < BM) {
+    float4 fa[NG][MT], fb[NG][NT];
 #pragma unroll
-      for (int k = 0; k < BK; ++k) colacc += As[k * GA::MC_LD + threadIdx.x];
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a) fa[g][a] = frag_read<BM, BK, AKC>(As, wm * WTM + a * 32 + li, g, lh);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) fb[g][b] = frag_read<BN, BK, BKC>(Bs, wn * WTN + b * 32 + li, g, lh);
+    }
+    if (!AKC) {
+      if (do_colsum && threadIdx.x < BM) {
+#pragma unroll
+        for (int k = 0; k < BK; ++k) colacc += As[k * GA::MC_LD + threadIdx.x];
+      }
     }
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      float4 fa[MT], fb[NT];
-#pragma unroll
-      for (int a = 0; a < MT; ++a) fa[a] = frag_read<BM, BK>(As, a_kc, wm * WTM + a * 32 + li, g, lh);
-#pragma unroll
-      for (int b = 0; b < NT; ++b) fb[b] = frag_read<BN, BK>(Bs, b_kc, wn * WTN + b * 32 + li, g, lh);
+    for (int g = 0; g < NG; ++g) {
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][a].x, fb[g][b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][a].y, fb[g][b].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][a].z, fb[g][b].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][a].w, fb[g][b].w, acc[a][b], 0, 0, 0);
         }
     }
     if (step + 1 < steps) {
       float* An = smem + (cur ^ 1) * (GA::SZ + GB::SZ);
-      tile_store<BM, BK>(An, a_kc, ra);
-      tile_store<BN, BK>(An + GA::SZ, b_kc, rb);
+      tile_store<BM, BK, AKC>(An, ra);
+      tile_store<BN, BK, BKC>(An + GA::SZ, rb);
     }
     __syncthreads();
   }
 
   // ---- epilogue ----
-  if (do_colsum && threadIdx.x < BM && (m0 + (int)threadIdx.x) < M && steps > 0)
-    atomicAdd(D.colsum + m0 + threadIdx.x, colacc);
-
+  if (!AKC) {
+    if (do_colsum && threadIdx.x < BM && (m0 + (int)threadIdx.x) < M && steps > 0)
+      atomicAdd(D.colsum + m0 + threadIdx.x, colacc);
+  }
   const bool first = (kz == 0);
   const float alpha = D.alpha;
   const int flags = D.flags;
+  const float* __restrict__ bias = D.bias;
+  const float* __restrict__ resid = D.residual;
+  const float* __restrict__ rsrc = D.relu_src;
+  float* __restrict__ Cp = D.C;
+  const int ldc = D.ldc;
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
       const int col = n0 + wn * WTN + b * 32 + li;
       if (col >= N) continue;
-      const float bv = (D.bias != nullptr && first) ? D.bias[col] : 0.f;
+      const float bv = (bias != nullptr && first) ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= M) continue;
-        const int64_t o = (int64_t)row * D.ldc + col;
+        const int64_t o = (int64_t)row * ldc + col;
         float v = alpha * acc[a][b][r] + bv;
-        if (D.residual != nullptr && first) v += D.residual[o];
+        if (resid != nullptr && first) v += resid[o];
         if (flags & NAST_GEMM_RELU) v = fmaxf(v, 0.f);
-        if (D.relu_src != nullptr) v = D.relu_src[o] > 0.f ? v : 0.f;
-        if (flags & NAST_GEMM_ATOMIC) atomicAdd(D.C + o, v);
-        else if (flags & NAST_GEMM_ACCUM) D.C[o] += v;
-        else D.C[o] = v;
+        if (rsrc != nullptr) v = rsrc[o] > 0.f ? v : 0.f;
+        if (flags & NAST_GEMM_ATOMIC) atomicAdd(Cp + o, v);
+        else if (flags & NAST_GEMM_ACCUM) Cp[o] += v;
+        else Cp[o] = v;
       }
     }
+}
+
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) {
+  using GA = TileGeom<BM, BK>;
+  using GB = TileGeom<BN, BK>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (GA::SZ + GB::SZ)];
+  // ---- which problem / tile / k-slice ----
+  const int bid = blockIdx.x;
+  int gi = 0;
+  while (gi + 1 < P.count && bid >= P.tile_start[gi + 1]) ++gi;
+  const nast_gemm_desc& D = P.d[gi];
+  const int local = bid - P.tile_start[gi];
+  const int tn = local % P.tiles_n[gi];
+  const int tq = local / P.tiles_n[gi];
+  const int tm = tq % P.tiles_m[gi];
+  const int kz = tq / P.tiles_m[gi];
+  const int per = P.kt_per_split[gi];
+  const bool a_kc = (D.transA == 0), b_kc = (D.transB != 0);
+  if (a_kc && b_kc) gemm_tile<BM, BN, BK, true, true>(D, tm, tn, kz, per, smem);          // y = x W^T
+  else if (a_kc && !b_kc) gemm_tile<BM, BN, BK, true, false>(D, tm, tn, kz, per, smem);   // dx = dy W, soft x E
+  else if (!a_kc && !b_kc) gemm_tile<BM, BN, BK, false, false>(D, tm, tn, kz, per, smem); // dW = dy^T x
+  else gemm_tile<BM, BN, BK, false, true>(D, tm, tn, kz, per, smem);
+}
+
+// -------------------------------------------------------------------------------------------------
+// "Skinny" variant for M <= 128 in the y = x W^T layout (greedy skip decoding: M = batch).  Latency-, not
+// MFMA-bound: a 32x32 output tile per workgroup, K split over the 4 wavefronts, and every wavefront loads
+// its fragments straight from global memory into registers in bursts of 64 k (no LDS staging, no barrier
+// in the K loop: one memory round trip per burst instead of one per K-tile), then the four partial
+// accumulators are summed through LDS.  Lane (i, h) holds k = 16*dg + 8*h + s for MFMA step s of the
+// 16-wide group dg (the same permutation for A and B), i.e. 32 contiguous bytes per lane.
+// -------------------------------------------------------------------------------------------------
+struct SkinnyLaunch {
+  nast_gemm_desc d[NAST_GEMM_MAX_GROUP];
+  int tile_start[NAST_GEMM_MAX_GROUP + 1];
+  int tiles_n[NAST_GEMM_MAX_GROUP];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void nast_gemm_f32_skinny_kernel(const SkinnyLaunch P) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 32 * 33];
+  const int bid = blockIdx.x;
+  int gi = 0;
+  while (gi + 1 < P.count && bid >= P.tile_start[gi + 1]) ++gi;
+  const nast_gemm_desc& D = P.d[gi];
+  const int local = bid - P.tile_start[gi];
+  const int tn = local % P.tiles_n[gi], tm = local / P.tiles_n[gi];
+  const int M = D.M, N = D.N, K = D.K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int arow = tm * 32 + li, brow = tn * 32 + li;
+  const bool aok = arow < M, bok = brow < N;
+  const float* __restrict__ Ap = D.A[0] + (int64_t)(aok ? arow : 0) * D.lda;
+  const float* __restrict__ Bp = D.B[0] + (int64_t)(bok ? brow : 0) * D.ldb;
+  // K slice of this wavefront, in 16-wide groups
+  const int ngroups = (K + 15) / 16;
+  const int gper = (ngroups + 3) / 4;
+  const int g_lo = wave * gper;
+  int g_hi = g_lo + gper;
+  if (g_hi > ngroups) g_hi = ngroups;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  constexpr int CH = 4;   // groups per burst: 64 k
+  auto load8 = [&](const float* __restrict__ base, bool ok, int g, float (&dst)[8]) {
+    const int k0 = g * 16 + lh * 8;
+    if (ok && g < g_hi && k0 + 8 <= K) {
+      const float4 u = *reinterpret_cast<const float4*>(base + k0);
+      const float4 w = *reinterpret_cast<const float4*>(base + k0 + 4);
+      dst[0] = u.x; dst[1] = u.y; dst[2] = u.z; dst[3] = u.w; dst[4] = w.x; dst[5] = w.y; dst[6] = w.z; dst[7] = w.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = (ok && g < g_hi && k0 + e < K) ? base[k0 + e] : 0.f;
+    }
+  };
+  float fa[CH][8], fb[CH][8];
+  const bool fuse_ln = D.ln_gamma != nullptr;       // host guarantees K <= 64*CH... one burst per wavefront
+  for (int g0 = g_lo; g0 < g_hi || (fuse_ln && g0 == g_lo); g0 += CH) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      load8(Ap, aok, g0 + c, fa[c]);
+      load8(Bp, bok, g0 + c, fb[c]);
+    }
+    if (fuse_ln) {
+      // LayerNorm of the A rows inside the GEMM: row statistics are reduced over the two lane halves and the four
+      // wavefronts (each holds a K slice of row li) through LDS; two-pass mean / variance like nast_ln_fwd_kernel
+      float s1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += fa[c][e];
+      s1 += __shfl_xor(s1, 32, 64);
+      if (lh == 0) red[wave * 32 + li] = s1;
+      __syncthreads();
+      const float mu = (red[li] + red[32 + li] + red[64 + li] + red[96 + li]) / K;
+      float s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = (g0 + c) * 16 + lh * 8 + e;
+          const float t = (g0 + c < g_hi && k < K) ? fa[c][e] - mu : 0.f;
+          s2 += t * t;
+        }
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lh == 0) red[128 + wave * 32 + li] = s2;
+      __syncthreads();
+      const float rs = rsqrtf((red[128 + li] + red[160 + li] + red[192 + li] + red[224 + li]) / K + 1e-6f);
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = (g0 + c) * 16 + lh * 8 + e;
+          const bool ok = aok && (g0 + c < g_hi) && k < K;
+          fa[c][e] = ok ? (fa[c][e] - mu) * rs * D.ln_gamma[k] + D.ln_beta[k] : 0.f;
+        }
+      __syncthreads();   // red[] is reused by the accumulator reduction below
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][e], fb[c][e], acc, 0, 0, 0);
+  }
+  // cross-wavefront reduction: red[wave][row][col] (row stride 33)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    red[(wave * 32 + row) * 33 + li] = acc[r];
+  }
+  __syncthreads();
+  const float alpha = D.alpha;
+  const int flags = D.flags;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = threadIdx.x + 256 * e;        // 0..1023
+    const int row = idx >> 5, col = idx & 31;
+    const int gr = tm * 32 + row, gc = tn * 32 + col;
+    if (gr >= M || gc >= N) continue;
+    float v = red[row * 33 + col] + red[(32 + row) * 33 + col] + red[(64 + row) * 33 + col] + red[(96 + row) * 33 + col];
+    v *= alpha;
+    if (D.bias) v += D.bias[gc];
+    const int64_t o = (int64_t)gr * D.ldc + gc;
+    if (D.residual) v += D.residual[o];
+    if (flags & NAST_GEMM_RELU) v = fmaxf(v, 0.f);
+    if (flags & NAST_GEMM_ACCUM) D.C[o] += v;
+    else D.C[o] = v;
+  }
+}
+
+static bool skinny_ok(const nast_gemm_desc* descs, int count) {
+  for (int i = 0; i < count; ++i) {
+    const nast_gemm_desc& D = descs[i];
+    if (D.M > 128 || D.transA != 0 || D.transB == 0 || D.nsrc != 1 || D.relu_src || D.colsum || (D.flags & NAST_GEMM_ATOMIC)) return false;
+    if (D.ln_gamma && (D.K > 256 || !D.ln_beta)) return false;
+    if ((D.lda & 3) || (D.ldb & 3) || (reinterpret_cast<uintptr_t>(D.A[0]) & 15) || (reinterpret_cast<uintptr_t>(D.B[0]) & 15)) return false;
+  }
+  return true;
+}
+
+static void launch_skinny(const nast_gemm_desc* descs, int count, hipStream_t stream) {
+  SkinnyLaunch P;
+  P.count = count;
+  int start = 0;
+  for (int i = 0; i < count; ++i) {
+    P.d[i] = descs[i];
+    P.tiles_n[i] = (descs[i].N + 31) / 32;
+    P.tile_start[i] = start;
+    start += P.tiles_n[i] * ((descs[i].M + 31) / 32);
+  }
+  for (int i = count; i <= NAST_GEMM_MAX_GROUP; ++i) P.tile_start[i] = start;
+  if (start == 0) return;
+  hipLaunchKernelGGL(nast_gemm_f32_skinny_kernel, dim3(start), dim3(256), 0, stream, P);
 }
 
 template <int BM, int BN, int BK>
@@ -245,18 +418,30 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
     tiles += P.tiles_m[i] * P.tiles_n[i];
   }
   if (dry) { *total_tiles = tiles; return 0; }
-  // split-K only for atomically accumulated outputs (wgrad): aim for >= ~2 workgroups per CU
+  // split-K: atomically accumulated outputs (wgrad) always qualify; plain outputs qualify when the problem is
+  // K-heavy (generator dgrad, soft-token x embedding: K = vocabulary) -- C is then zeroed here and every K
+  // slice adds atomically (bias/residual are added by slice 0).  Aim for >= ~2 workgroups per CU.
   int want = tiles > 0 ? (512 + tiles - 1) / tiles : 1;
   if (want > 32) want = 32;
   int start = 0;
   for (int i = 0; i < count; ++i) {
     const int nkt = (descs[i].K + BK - 1) / BK;
     int sk = 1;
-    if ((descs[i].flags & NAST_GEMM_ATOMIC) && descs[i].nsrc == 1 && descs[i].relu_src == nullptr &&
-        !(descs[i].flags & NAST_GEMM_RELU)) {
+    const bool plain_epilogue = descs[i].nsrc == 1 && descs[i].relu_src == nullptr && !(descs[i].flags & NAST_GEMM_RELU);
+    if ((descs[i].flags & NAST_GEMM_ATOMIC) && plain_epilogue) {
       sk = want;
       const int max_sk = nkt / 4 > 0 ? nkt / 4 : 1;   // at least 4 K-tiles per slice
       if (sk > max_sk) sk = max_sk;
+    } else if (plain_epilogue && !(descs[i].flags & NAST_GEMM_ACCUM) && want >= 2 && nkt >= 32) {
+      sk = want;
+      const int max_sk = nkt / 8;                      // at least 8 K-tiles per slice
+      if (sk > max_sk) sk = max_sk;
+      if (sk >= 2) {
+        hipMemset2DAsync(descs[i].C, (size_t)descs[i].ldc * 4, 0, (size_t)descs[i].N * 4, descs[i].M, stream);
+        P.d[i].flags |= NAST_GEMM_ATOMIC;
+      } else {
+        sk = 1;
+      }
     }
     int per = (nkt + sk - 1) / sk;
     if (per < 1) per = 1;
@@ -291,10 +476,14 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
     NAST_REQUIRE(!((D.flags & NAST_GEMM_ATOMIC) && (D.flags & NAST_GEMM_ACCUM)), "nast_gemm_f32[%d]: ATOMIC and ACCUM are exclusive", i);
     flops += 2.0 * D.M * D.N * (double)D.K * D.nsrc;
   }
+  const bool skinny = skinny_ok(descs, count);
+  for (int i = 0; i < count; ++i)
+    NAST_REQUIRE(descs[i].ln_gamma == nullptr || skinny, "nast_gemm_f32[%d]: fused LayerNorm needs the small-M path (M<=128, K<=256, x W^T)", i);
   int tilesL = 0;
   plan_and_launch<128, 128, 16>(descs, count, stream, true, &tilesL);
   nast_prof_before(1, stream);
-  if (tilesL >= 384) plan_and_launch<128, 128, 16>(descs, count, stream, false, nullptr);
+  if (skinny) launch_skinny(descs, count, stream);
+  else if (tilesL >= 384) plan_and_launch<128, 128, 16>(descs, count, stream, false, nullptr);
   else plan_and_launch<64, 64, 32>(descs, count, stream, false, nullptr);
   nast_prof_after(1, stream, flops);
   NAST_CHECK_LAUNCH("nast_gemm_f32");

@@ -9,7 +9,8 @@ __global__ __launch_bounds__(256) void nast_lp_step_kernel(const float* __restri
                                                            const float* __restrict__ cand_in, const float* __restrict__ unk,
                                                            const float* __restrict__ pos_w, const int64_t* __restrict__ olen_,
                                                            int64_t* __restrict__ now_pos, int64_t* __restrict__ allpos,
-                                                           float* __restrict__ x_next, int B, int S1, int d, int step,
+                                                           float* __restrict__ x_next, const float* __restrict__ norm_w,
+                                                           const float* __restrict__ norm_b, int B, int S1, int d, int step,
                                                            int ldp, float sqrt_d, int write_next) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -19,8 +20,18 @@ __global__ __launch_bounds__(256) void nast_lp_step_kernel(const float* __restri
   const float* q = qh + (int64_t)b * d;
   const float* hrow = hid + (int64_t)b * d;
   float dot[4] = {0.f, 0.f, 0.f, 0.f}, lin[4] = {0.f, 0.f, 0.f, 0.f};
+  float mu = 0.f, rs = 1.f;
+  if (norm_w) {   // `hid` is the un-normalised decoder output: apply HiddenDecoder.norm here (transformer.py:376)
+    float s1 = 0.f;
+    for (int c = lane; c < d; c += 64) s1 += hrow[c];
+    mu = wave_sum(s1) / d;
+    float s2 = 0.f;
+    for (int c = lane; c < d; c += 64) { const float t = hrow[c] - mu; s2 += t * t; }
+    rs = rsqrtf(wave_sum(s2) / d + 1e-6f);
+  }
   for (int c = lane; c < d; c += 64) {
-    const float qv = q[c], hv = hrow[c];
+    const float qv = q[c];
+    const float hv = norm_w ? (hrow[c] - mu) * rs * norm_w[c] + norm_b[c] : hrow[c];
     dot[0] = fmaf(qv, kunk[c], dot[0]);
 #pragma unroll
     for (int j = 1; j < 4; ++j) dot[j] = fmaf(qv, KC[((int64_t)b * NC + now + j) * d + c], dot[j]);
@@ -57,7 +68,8 @@ __global__ __launch_bounds__(256) void nast_lp_step_kernel(const float* __restri
 
 extern "C" int nast_lp_step_f32(const float* qh, const float* hid, const float* KC, const float* kunk, const float* lin_w,
                                 const float* lin_b, const float* cand_in, const float* unk, const float* pos_w,
-                                const int64_t* origin_length, int64_t* now_pos, int64_t* allpos, float* x_next, int B, int S1,
+                                const int64_t* origin_length, int64_t* now_pos, int64_t* allpos, float* x_next,
+                                const float* norm_w, const float* norm_b, int B, int S1,
                                 int d, int step, int ldp, int write_next, void* stream) {
   NAST_REQUIRE(B >= 0 && S1 >= 1 && d >= 1 && step >= 0 && ldp >= step + 2, "nast_lp_step_f32: bad sizes");
   if (B == 0) return NAST_OK;
@@ -65,7 +77,7 @@ extern "C" int nast_lp_step_f32(const float* qh, const float* hid, const float* 
                "nast_lp_step_f32: NULL pointer");
   NAST_REQUIRE(!write_next || x_next, "nast_lp_step_f32: x_next NULL");
   hipLaunchKernelGGL(nast_lp_step_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, qh, hid, KC, kunk, lin_w, lin_b,
-                     cand_in, unk, pos_w, origin_length, now_pos, allpos, x_next, B, S1, d, step, ldp, sqrtf((float)d),
+                     cand_in, unk, pos_w, origin_length, now_pos, allpos, x_next, norm_w, norm_b, B, S1, d, step, ldp, sqrtf((float)d),
                      write_next);
   NAST_CHECK_LAUNCH("nast_lp_step_f32");
   return NAST_OK;

@@ -469,6 +469,44 @@ class LengthPredictor(nn.Module):
                                               unk_id=unk_id)
             return ops.align_viterbi(cost0, cost, origin_length, target_length)
 
+    def _native_decode(self, memory, origin_length, eos, unk, allpos_buf):
+        from ._lib import DecLayerWeights, LPDecodeArgs, load
+        import ctypes as C
+        lib = load()
+        B, S1, d = memory.shape
+        L = self.args.max_length
+        layers = self.decoder.layers
+        dff = layers[0].pw_ffn.mlp[0].weight.shape[0]
+        arr = (DecLayerWeights * len(layers))()
+        for i, l in enumerate(layers):
+            sa, ca, f, sl = l.self_attn, l.src_attn, l.pw_ffn.mlp, l.sublayer
+            vals = [sl[0].layer_norm.weight, sl[0].layer_norm.bias,
+                    sa.head_projs[0].weight, sa.head_projs[0].bias, sa.head_projs[1].weight, sa.head_projs[1].bias,
+                    sa.head_projs[2].weight, sa.head_projs[2].bias, sa.fc.weight, sa.fc.bias,
+                    sl[1].layer_norm.weight, sl[1].layer_norm.bias,
+                    ca.head_projs[0].weight, ca.head_projs[0].bias, ca.head_projs[1].weight, ca.head_projs[1].bias,
+                    ca.head_projs[2].weight, ca.head_projs[2].bias, ca.fc.weight, ca.fc.bias,
+                    sl[2].layer_norm.weight, sl[2].layer_norm.bias, f[0].weight, f[0].bias, f[3].weight, f[3].bias]
+            for (name, _), v in zip(DecLayerWeights._fields_, vals):
+                setattr(arr[i], name, v.data_ptr())
+        nbytes = lib.nast_lp_decode_workspace_bytes(B, S1, d, dff, L, len(layers))
+        ws = torch.empty(nbytes // 4 + 64, device=memory.device, dtype=torch.float32)
+        memory, origin_length, eos, unk = memory.contiguous(), origin_length.contiguous(), eos.contiguous(), unk.contiguous()
+        a = LPDecodeArgs()
+        a.B, a.S1, a.d, a.h, a.dff, a.L, a.nlayers = B, S1, d, layers[0].self_attn.h, dff, L, len(layers)
+        a.layers = arr
+        a.norm_w, a.norm_b = self.decoder.norm.weight.data_ptr(), self.decoder.norm.bias.data_ptr()
+        a.wq_w, a.wq_b, a.wk_w, a.wk_b = (t.data_ptr() for t in (self.wq.weight, self.wq.bias, self.wk.weight, self.wk.bias))
+        a.lin_w, a.lin_b = self.linear.weight.data_ptr(), self.linear.bias.data_ptr()
+        a.pos_w = self.pos_embed.weight.data_ptr()
+        a.eos, a.unk = eos.data_ptr(), unk.data_ptr()
+        a.memory, a.origin_length, a.allpos = memory.data_ptr(), origin_length.data_ptr(), allpos_buf.data_ptr()
+        off = (-ws.data_ptr()) % 256
+        a.workspace = ws.data_ptr() + off
+        steps = C.c_int(0)
+        ops.call("nast_lp_decode_f32", C.byref(a), C.byref(steps), ops._stream())
+        return steps.value
+
     # -- forward ------------------------------------------------------------------------------
     def forward(self, origin_input, origin_length, origin_token=None, target_token=None, target_length=None, embed=None,
                 *, use_inference_z, origin_soft_rows=None):
@@ -517,33 +555,13 @@ class LengthPredictor(nn.Module):
         if not use_inference_z:
             return origin_input, origin_length                                # :521-522 (as the reference)
 
-        # ---- greedy skip decoding (:525-570) ----
+        # ---- greedy skip decoding (:525-570): the whole loop runs in native code (nast_lp_decode_f32) ----
+        if self.args.z_decode_mode != "max":
+            raise NotImplementedError("z_decode_mode='sample' is not implemented on the HIP path (reference default: max)")
         L = self.args.max_length
         with torch.no_grad():
-            oin = origin_input.detach()
-            cand_idx = torch.arange(S1 + 5, device=dev).unsqueeze(0).expand(batch_size, -1).contiguous()
-            cand_in = ops.lp_gather(oin, origin_length, cand_idx, eos_embed.detach(), unk_embed.detach(), None, 0, False)
-            KC = self.wk(cand_in)
-            kunk = self.wk(unk_embed.detach().view(1, d)).view(d)
-            unk_d = unk_embed.detach().contiguous()
-            now_pos = torch.zeros(batch_size, dtype=torch.long, device=dev)
-            allpos_buf = torch.zeros(batch_size, L + 1, dtype=torch.long, device=dev)
-            cache = KVCacheDecoder(self.decoder, oin, src_mask, L)
-            x = (oin[:, 0] + self.pos_embed.weight[0]).contiguous()           # step-0 input: cand_in[b,0] + pos[0]
-            x_next = torch.empty_like(x)
-            olen = origin_length.contiguous()
-            steps = 0
-            for k in range(L):
-                hid = cache.step(x, k)
-                qh = self.wq(hid)
-                ops.call("nast_lp_step_f32", qh.data_ptr(), hid.data_ptr(), KC.data_ptr(), kunk.data_ptr(),
-                         self.linear.weight.data_ptr(), self.linear.bias.data_ptr(), cand_in.data_ptr(), unk_d.data_ptr(),
-                         self.pos_embed.weight.data_ptr(), olen.data_ptr(), now_pos.data_ptr(), allpos_buf.data_ptr(),
-                         x_next.data_ptr(), batch_size, S1, d, k, L + 1, 1 if k + 1 < L else 0, ops._stream())
-                x, x_next = x_next, x
-                steps = k + 1
-                if k % 5 == 0 and (now_pos >= (origin_length + 1)).sum().tolist() == batch_size:     # :569
-                    break
+            allpos_buf = torch.empty(batch_size, L + 1, dtype=torch.long, device=dev)
+            steps = self._native_decode(origin_input.detach(), origin_length, eos_embed.detach(), unk_embed.detach(), allpos_buf)
             allpos = allpos_buf[:, :steps + 1].contiguous()
         dec_input = ops.lp_gather(origin_input, origin_length, allpos, eos_embed, unk_embed, None, 0, True)   # :576-578
         target_length = (allpos < (origin_length + 1).unsqueeze(-1)).sum(dim=1) - 1                  # :580

@@ -259,3 +259,19 @@ def test_misc():
     g = load_golden("g10_misc")
     assert np.array_equal(O.get_lengths(T(g["get_lengths/in"]), 2).numpy(), g["get_lengths/out"])
     close(O.generate_mask(5, g["generateMask/len"]), g["generateMask/out"])
+
+
+def test_c_alignment_oracle():
+    """The plain-C restatement agrees with the golden allpos and with the numpy restatement on random ties."""
+    from oracle import c_align
+    g = load_golden("g6_match")
+    for name in g["cases"]:
+        name = str(name)
+        ap = c_align.viterbi_align(g[f"{name}/cost0"], g[f"{name}/cost"], g[f"{name}/src_len"], g[f"{name}/tgt_len"])
+        assert np.array_equal(ap, g[f"{name}/allpos"]), name
+    rng = np.random.default_rng(0)
+    for B, T_, S in ((16, 9, 11), (8, 33, 32), (4, 70, 90)):
+        cost = (np.round(rng.random((B, T_, S)) * 8) / 4).astype(np.float32)
+        cost0 = (np.round(rng.random((B, T_)) * 8) / 4).astype(np.float32)
+        ol, tl = rng.integers(1, S + 1, size=B), rng.integers(1, T_ + 1, size=B)
+        assert np.array_equal(c_align.viterbi_align(cost0, cost, ol, tl), O.viterbi_align(cost0, cost, ol, tl))

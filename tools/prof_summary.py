@@ -1,0 +1,9 @@
+"""Summarise a rocprofv3 --kernel-trace --stats output dir: per-kernel totals per step."""
+import csv, glob, sys
+d, steps = sys.argv[1], float(sys.argv[2])
+f = glob.glob(d + '/*/*kernel_stats.csv')[0]
+rows = list(csv.DictReader(open(f)))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+print(f"kernel time per step: {tot/1e6/steps:.2f} ms ; launches per step: {sum(int(r['Calls']) for r in rows)/steps:.0f}")
+for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 16]:
+    print(f"{r['Name'][:84]:84s} calls/step={int(r['Calls'])/steps:7.1f} ms/step={float(r['TotalDurationNs'])/1e6/steps:7.3f} avg_us={float(r['AverageNs'])/1e3:8.2f} {float(r['Percentage']):5.1f}%")
