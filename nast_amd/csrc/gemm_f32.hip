@@ -36,7 +36,7 @@ struct TileGeom {
 };
 
 // global -> registers.  `rows` bounds the tile's row index, K bounds k.  KC = k-contiguous source.
-template <int R, int BK, bool KC>
+template <int R, int BK, bool KC, bool FAST>
 __device__ __forceinline__ void tile_load(const float* __restrict__ src, int ld, bool vec,
                                           int row0, int rows, int k0, int K, float4 (&reg)[TileGeom<R, BK>::NV]) {
   const int tid = threadIdx.x;
@@ -44,7 +44,22 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ src, int ld,
   for (int j = 0; j < TileGeom<R, BK>::NV; ++j) {
     const int c = tid + 256 * j;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KC) {
+    if (FAST) {
+      // host-checked: 16-B aligned base, ld % 4 == 0, K % BK == 0 and (m-contiguous operands) rows % 4 == 0.
+      // Rows past the edge are clamped to the last valid ones: they only feed output elements that the
+      // epilogue never stores, and an unconditional load lets the wait sink down to the LDS store.
+      if (KC) {
+        const int row = c / (BK / 4), kc = (c % (BK / 4)) * 4;
+        int gr = row0 + row;
+        gr = gr < rows ? gr : rows - 1;
+        v = *reinterpret_cast<const float4*>(src + (int64_t)gr * ld + k0 + kc);
+      } else {
+        const int krow = c / (R / 4), mc = (c % (R / 4)) * 4;
+        int gr = row0 + mc;
+        gr = gr < rows ? gr : rows - 4;
+        v = *reinterpret_cast<const float4*>(src + (int64_t)(k0 + krow) * ld + gr);
+      }
+    } else if (KC) {
       const int row = c / (BK / 4), kc = (c % (BK / 4)) * 4;
       const int gr = row0 + row, gk = k0 + kc;
       if (gr < rows && gk < K) {
@@ -108,7 +123,7 @@ __device__ __forceinline__ float4 frag_read(const float* __restrict__ lds, int r
 
 // One output tile (and K slice) of one problem; operand layouts are compile-time so that the K loop is
 // branch-free: all fragment reads of a K-tile are issued first, then the MFMAs run back to back.
-template <int BM, int BN, int BK, bool AKC, bool BKC>
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool FAST>
 __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int tn, int kz, int kt_per_split, float* smem) {
   using GA = TileGeom<BM, BK>;
   using GB = TileGeom<BN, BK>;
@@ -145,8 +160,8 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
     const int kt = kt_lo + step - s * nk;
     const float* Ap = D.A[s];
     const float* Bp = D.B[s];
-    tile_load<BM, BK, AKC>(Ap, D.lda, va && ((reinterpret_cast<uintptr_t>(Ap) & 15) == 0), m0, M, kt * BK, K, ra);
-    tile_load<BN, BK, BKC>(Bp, D.ldb, vb && ((reinterpret_cast<uintptr_t>(Bp) & 15) == 0), n0, N, kt * BK, K, rb);
+    tile_load<BM, BK, AKC, FAST>(Ap, D.lda, va && ((reinterpret_cast<uintptr_t>(Ap) & 15) == 0), m0, M, kt * BK, K, ra);
+    tile_load<BN, BK, BKC, FAST>(Bp, D.ldb, vb && ((reinterpret_cast<uintptr_t>(Bp) & 15) == 0), n0, N, kt * BK, K, rb);
   };
 
   if (steps > 0) {
@@ -209,30 +224,45 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
   const float* __restrict__ rsrc = D.relu_src;
   float* __restrict__ Cp = D.C;
   const int ldc = D.ldc;
+  const bool has_res = resid != nullptr && first;
+  const bool has_rsrc = rsrc != nullptr;
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
       const int col = n0 + wn * WTN + b * 32 + li;
-      if (col >= N) continue;
-      const float bv = (bias != nullptr && first) ? bias[col] : 0.f;
+      const bool col_ok = col < N;
+      const int colc = col_ok ? col : N - 1;
+      const float bv = (bias != nullptr && first) ? bias[colc] : 0.f;
+      const int rbase = m0 + wm * WTM + a * 32 + 4 * lh;
+      // gather the epilogue operands of all 16 rows first (clamped, unconditional), then combine and store:
+      // one memory round trip per 32x32 tile instead of one per element
+      float rv[16], sv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= M) continue;
+        int row = rbase + (r & 3) + 8 * (r >> 2);
+        row = row < M ? row : M - 1;
+        const int64_t o = (int64_t)row * ldc + colc;
+        rv[r] = has_res ? resid[o] : 0.f;
+        sv[r] = has_rsrc ? rsrc[o] : 1.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
         const int64_t o = (int64_t)row * ldc + col;
-        float v = alpha * acc[a][b][r] + bv;
-        if (resid != nullptr && first) v += resid[o];
+        float v = alpha * acc[a][b][r] + bv + rv[r];
         if (flags & NAST_GEMM_RELU) v = fmaxf(v, 0.f);
-        if (rsrc != nullptr) v = rsrc[o] > 0.f ? v : 0.f;
-        if (flags & NAST_GEMM_ATOMIC) atomicAdd(Cp + o, v);
-        else if (flags & NAST_GEMM_ACCUM) Cp[o] += v;
-        else Cp[o] = v;
+        v = sv[r] > 0.f ? v : 0.f;
+        if (col_ok && row < M) {
+          if (flags & NAST_GEMM_ATOMIC) atomicAdd(Cp + o, v);
+          else if (flags & NAST_GEMM_ACCUM) Cp[o] += v;
+          else Cp[o] = v;
+        }
       }
     }
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, bool FAST>
 __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) {
   using GA = TileGeom<BM, BK>;
   using GB = TileGeom<BN, BK>;
@@ -249,10 +279,10 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
   const int kz = tq / P.tiles_m[gi];
   const int per = P.kt_per_split[gi];
   const bool a_kc = (D.transA == 0), b_kc = (D.transB != 0);
-  if (a_kc && b_kc) gemm_tile<BM, BN, BK, true, true>(D, tm, tn, kz, per, smem);          // y = x W^T
-  else if (a_kc && !b_kc) gemm_tile<BM, BN, BK, true, false>(D, tm, tn, kz, per, smem);   // dx = dy W, soft x E
-  else if (!a_kc && !b_kc) gemm_tile<BM, BN, BK, false, false>(D, tm, tn, kz, per, smem); // dW = dy^T x
-  else gemm_tile<BM, BN, BK, false, true>(D, tm, tn, kz, per, smem);
+  if (a_kc && b_kc) gemm_tile<BM, BN, BK, true, true, FAST>(D, tm, tn, kz, per, smem);          // y = x W^T
+  else if (a_kc && !b_kc) gemm_tile<BM, BN, BK, true, false, FAST>(D, tm, tn, kz, per, smem);   // dx = dy W, soft x E
+  else if (!a_kc && !b_kc) gemm_tile<BM, BN, BK, false, false, FAST>(D, tm, tn, kz, per, smem); // dW = dy^T x
+  else gemm_tile<BM, BN, BK, false, true, FAST>(D, tm, tn, kz, per, smem);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -407,6 +437,19 @@ static void launch_skinny(const nast_gemm_desc* descs, int count, hipStream_t st
 }
 
 template <int BM, int BN, int BK>
+static bool fast_ok(const nast_gemm_desc* descs, int count) {
+  for (int i = 0; i < count; ++i) {
+    const nast_gemm_desc& D = descs[i];
+    if (D.M < 4 || D.N < 4 || D.K % BK != 0 || (D.lda & 3) || (D.ldb & 3)) return false;
+    if (D.transA && (D.M & 3)) return false;
+    if (!D.transB && (D.N & 3)) return false;
+    for (int s = 0; s < D.nsrc; ++s)
+      if ((reinterpret_cast<uintptr_t>(D.A[s]) & 15) || (reinterpret_cast<uintptr_t>(D.B[s]) & 15)) return false;
+  }
+  return true;
+}
+
+template <int BM, int BN, int BK>
 static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t stream, bool dry, int* total_tiles) {
   GemmLaunch P;
   P.count = count;
@@ -418,43 +461,73 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
     tiles += P.tiles_m[i] * P.tiles_n[i];
   }
   if (dry) { *total_tiles = tiles; return 0; }
-  // split-K: atomically accumulated outputs (wgrad) always qualify; plain outputs qualify when the problem is
-  // K-heavy (generator dgrad, soft-token x embedding: K = vocabulary) -- C is then zeroed here and every K
-  // slice adds atomically (bias/residual are added by slice 0).  Aim for >= ~2 workgroups per CU.
-  int want = tiles > 0 ? (512 + tiles - 1) / tiles : 1;
-  if (want > 32) want = 32;
-  int start = 0;
+  // split-K plan.  Work is counted in K-tiles per workgroup.  The group should (a) put >= ~3 workgroups on each
+  // of the 256 CUs and (b) give every workgroup about the same amount of work, so a K-heavy member (a weight
+  // gradient: K = all rows of the batch; the generator dgrad / soft-token embedding: K = vocabulary) is cut
+  // into slices no longer than the members that cannot be cut.  Atomically accumulated outputs are cut
+  // directly; plain outputs are zeroed here and switched to atomic adds (bias/residual go to slice 0).
+  constexpr int MIN_KT = 256 / BK;                       // at least K = 256 per slice
+  constexpr int TARGET_WGS = (BM >= 128) ? 768 : 1024;
+  int nkt_of[NAST_GEMM_MAX_GROUP];
+  bool can_split[NAST_GEMM_MAX_GROUP];
+  long long work = 0;
+  int max_unsplit = 0;
+  for (int i = 0; i < count; ++i) {
+    const nast_gemm_desc& D = descs[i];
+    nkt_of[i] = ((D.K + BK - 1) / BK) * D.nsrc;
+    const bool plain = D.relu_src == nullptr && !(D.flags & NAST_GEMM_RELU) && D.nsrc == 1;
+    can_split[i] = plain && ((D.flags & NAST_GEMM_ATOMIC) || (!(D.flags & NAST_GEMM_ACCUM) && nkt_of[i] >= 4 * MIN_KT));
+    work += (long long)P.tiles_m[i] * P.tiles_n[i] * nkt_of[i];
+    if (!can_split[i] && nkt_of[i] > max_unsplit) max_unsplit = nkt_of[i];
+  }
+  long long target = (work + TARGET_WGS - 1) / TARGET_WGS;
+  if (max_unsplit > 0 && target > max_unsplit) target = max_unsplit;
+  if (target < MIN_KT) target = MIN_KT;
+  // longest workgroups first (dispatch follows blockIdx): the tail of the launch is then made of short ones
+  int order[NAST_GEMM_MAX_GROUP];
+  int per_of[NAST_GEMM_MAX_GROUP], sk_of[NAST_GEMM_MAX_GROUP];
   for (int i = 0; i < count; ++i) {
     const int nkt = (descs[i].K + BK - 1) / BK;
     int sk = 1;
-    const bool plain_epilogue = descs[i].nsrc == 1 && descs[i].relu_src == nullptr && !(descs[i].flags & NAST_GEMM_RELU);
-    if ((descs[i].flags & NAST_GEMM_ATOMIC) && plain_epilogue) {
-      sk = want;
-      const int max_sk = nkt / 4 > 0 ? nkt / 4 : 1;   // at least 4 K-tiles per slice
-      if (sk > max_sk) sk = max_sk;
-    } else if (plain_epilogue && !(descs[i].flags & NAST_GEMM_ACCUM) && want >= 2 && nkt >= 32) {
-      sk = want;
-      const int max_sk = nkt / 8;                      // at least 8 K-tiles per slice
-      if (sk > max_sk) sk = max_sk;
-      if (sk >= 2) {
-        hipMemset2DAsync(descs[i].C, (size_t)descs[i].ldc * 4, 0, (size_t)descs[i].N * 4, descs[i].M, stream);
-        P.d[i].flags |= NAST_GEMM_ATOMIC;
-      } else {
-        sk = 1;
-      }
+    if (can_split[i]) {
+      sk = (int)((nkt + target - 1) / target);
+      if (sk < 1) sk = 1;
+      if (!(descs[i].flags & NAST_GEMM_ATOMIC) && sk < 2) sk = 1;
     }
     int per = (nkt + sk - 1) / sk;
     if (per < 1) per = 1;
     sk = (nkt + per - 1) / per;
     if (sk < 1) sk = 1;
-    P.splitk[i] = sk;
-    P.kt_per_split[i] = per;
-    P.tile_start[i] = start;
-    start += P.tiles_m[i] * P.tiles_n[i] * sk;
+    if (sk >= 2 && !(descs[i].flags & NAST_GEMM_ATOMIC)) {
+      if (descs[i].ldc == descs[i].N) hipMemsetAsync(descs[i].C, 0, (size_t)descs[i].M * descs[i].N * 4, stream);
+      else hipMemset2DAsync(descs[i].C, (size_t)descs[i].ldc * 4, 0, (size_t)descs[i].N * 4, descs[i].M, stream);
+      P.d[i].flags |= NAST_GEMM_ATOMIC;
+    }
+    per_of[i] = per; sk_of[i] = sk; order[i] = i;
   }
+  for (int a = 1; a < count; ++a)     // insertion sort by per-workgroup work, descending
+    for (int b = a; b > 0 && per_of[order[b]] * descs[order[b]].nsrc > per_of[order[b - 1]] * descs[order[b - 1]].nsrc; --b) {
+      const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t;
+    }
+  GemmLaunch Q = P;
+  int start = 0;
+  for (int j = 0; j < count; ++j) {
+    const int i = order[j];
+    Q.d[j] = P.d[i];
+    Q.tiles_m[j] = P.tiles_m[i];
+    Q.tiles_n[j] = P.tiles_n[i];
+    Q.splitk[j] = sk_of[i];
+    Q.kt_per_split[j] = per_of[i];
+    Q.tile_start[j] = start;
+    start += P.tiles_m[i] * P.tiles_n[i] * sk_of[i];
+  }
+  P = Q;
   for (int i = count; i <= NAST_GEMM_MAX_GROUP; ++i) P.tile_start[i] = start;
   if (start == 0) return 0;
-  hipLaunchKernelGGL((nast_gemm_f32_kernel<BM, BN, BK>), dim3(start), dim3(256), 0, stream, P);
+  if (fast_ok<BM, BN, BK>(descs, count))
+    hipLaunchKernelGGL((nast_gemm_f32_kernel<BM, BN, BK, true>), dim3(start), dim3(256), 0, stream, P);
+  else
+    hipLaunchKernelGGL((nast_gemm_f32_kernel<BM, BN, BK, false>), dim3(start), dim3(256), 0, stream, P);
   return 0;
 }
 

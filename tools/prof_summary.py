@@ -1,7 +1,8 @@
-"""Summarise a rocprofv3 --kernel-trace --stats output dir: per-kernel totals per step."""
+"""Summarise a rocprofv3 --kernel-trace --stats (csv) output dir: per-kernel totals per step.
+usage: prof_summary.py DIR STEPS [TOPN]"""
 import csv, glob, sys
 d, steps = sys.argv[1], float(sys.argv[2])
-f = glob.glob(d + '/*/*kernel_stats.csv')[0]
+f = (glob.glob(d + '/*kernel_stats.csv') + glob.glob(d + '/*/*kernel_stats.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print(f"kernel time per step: {tot/1e6/steps:.2f} ms ; launches per step: {sum(int(r['Calls']) for r in rows)/steps:.0f}")
