@@ -111,7 +111,7 @@ extern "C" int nast_lp_decode_f32(const nast_lp_decode_args* A, int* steps_out, 
   Ws w = carve(A->workspace, B, S1, d, dff, L, nl, h);
   const int NC = S1 + 5;
   const float scale = 1.0f / sqrtf((float)(d / h));
-  const bool fuse_ln = (B <= 128 && d <= 256 && (d & 3) == 0);
+  const bool fuse_ln = (B <= 1024 && d <= 256 && (d & 3) == 0);
 
   hipLaunchKernelGGL(lp_candidates_kernel, dim3(((int64_t)B * NC + 3) / 4), dim3(256), 0, s, A->memory, A->origin_length, A->eos,
                      w.cand, w.mask, B, S1, d);

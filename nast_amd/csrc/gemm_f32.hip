@@ -16,6 +16,10 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define NAST_GEMM_VEC_C (1 << 16)   // internal: C / bias / residual / relu_src allow 16-B accesses
+#ifndef NAST_BK128
+#define NAST_BK128 32
+#endif
 
 struct GemmLaunch {
   nast_gemm_desc d[NAST_GEMM_MAX_GROUP];
@@ -177,14 +181,13 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
     const float* Bs = As + GA::SZ;
     if (step + 1 < steps) issue(step + 1);
 
-    float4 fa[NG][MT], fb[NG][NT];
+    // fragments are double-buffered across the 8-wide k-groups: the LDS reads of group g+1 are in flight
+    // while the 4 x MT x NT MFMAs of group g issue
+    float4 fa[2][MT], fb[2][NT];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int a = 0; a < MT; ++a) fa[0][a] = frag_read<BM, BK, AKC>(As, wm * WTM + a * 32 + li, 0, lh);
 #pragma unroll
-      for (int a = 0; a < MT; ++a) fa[g][a] = frag_read<BM, BK, AKC>(As, wm * WTM + a * 32 + li, g, lh);
-#pragma unroll
-      for (int b = 0; b < NT; ++b) fb[g][b] = frag_read<BN, BK, BKC>(Bs, wn * WTN + b * 32 + li, g, lh);
-    }
+    for (int b = 0; b < NT; ++b) fb[0][b] = frag_read<BN, BK, BKC>(Bs, wn * WTN + b * 32 + li, 0, lh);
     if (!AKC) {
       if (do_colsum && threadIdx.x < BM) {
 #pragma unroll
@@ -193,14 +196,21 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+      const int c = g & 1, n = c ^ 1;
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) fa[n][a] = frag_read<BM, BK, AKC>(As, wm * WTM + a * 32 + li, g + 1, lh);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) fb[n][b] = frag_read<BN, BK, BKC>(Bs, wn * WTN + b * 32 + li, g + 1, lh);
+      }
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][a].x, fb[g][b].x, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][a].y, fb[g][b].y, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][a].z, fb[g][b].z, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g][a].w, fb[g][b].w, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].x, fb[c][b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].y, fb[c][b].y, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].z, fb[c][b].z, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].w, fb[c][b].w, acc[a][b], 0, 0, 0);
         }
     }
     if (step + 1 < steps) {
@@ -226,6 +236,53 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
   const int ldc = D.ldc;
   const bool has_res = resid != nullptr && first;
   const bool has_rsrc = rsrc != nullptr;
+  if (FAST && (flags & NAST_GEMM_VEC_C) && !(flags & NAST_GEMM_ATOMIC)) {
+    // Wide epilogue: each 32x32 accumulator tile is transposed through a wave-private LDS patch (the operand
+    // buffers are free after the loop's last barrier) so that a lane owns 4 consecutive columns: bias /
+    // residual / ReLU-mask loads and the C store are 16-B accesses, 4 store instructions per tile instead of 16.
+    constexpr int PLD = 36;
+    float* stg = smem + wave * (32 * PLD);
+    const bool has_bias = bias != nullptr && first;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * PLD + li] = acc[a][b][r];
+        const int c4 = (lane & 7) * 4;
+        const int col = n0 + wn * WTN + b * 32 + c4;
+        const bool col_ok = col < N;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_bias && col_ok) bv = *reinterpret_cast<const float4*>(bias + col);
+        float4 tv[4], rv[4], sv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int rl = p * 8 + (lane >> 3);
+          tv[p] = *reinterpret_cast<const float4*>(stg + rl * PLD + c4);
+          int row = m0 + wm * WTM + a * 32 + rl;
+          row = row < M ? row : M - 1;
+          const int64_t o = (int64_t)row * ldc + (col_ok ? col : 0);
+          rv[p] = has_res ? *reinterpret_cast<const float4*>(resid + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+          sv[p] = has_rsrc ? *reinterpret_cast<const float4*>(rsrc + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int row = m0 + wm * WTM + a * 32 + p * 8 + (lane >> 3);
+          float4 v;
+          v.x = alpha * tv[p].x + bv.x + rv[p].x; v.y = alpha * tv[p].y + bv.y + rv[p].y;
+          v.z = alpha * tv[p].z + bv.z + rv[p].z; v.w = alpha * tv[p].w + bv.w + rv[p].w;
+          if (flags & NAST_GEMM_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          v.x = sv[p].x > 0.f ? v.x : 0.f; v.y = sv[p].y > 0.f ? v.y : 0.f;
+          v.z = sv[p].z > 0.f ? v.z : 0.f; v.w = sv[p].w > 0.f ? v.w : 0.f;
+          if (col_ok && row < M) {
+            float4* cp = reinterpret_cast<float4*>(Cp + (int64_t)row * ldc + col);
+            if (flags & NAST_GEMM_ACCUM) { const float4 c0 = *cp; v.x += c0.x; v.y += c0.y; v.z += c0.z; v.w += c0.w; }
+            *cp = v;
+          }
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -286,7 +343,7 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
 }
 
 // -------------------------------------------------------------------------------------------------
-// "Skinny" variant for M <= 128 in the y = x W^T layout (greedy skip decoding: M = batch).  Latency-, not
+// "Skinny" variant for M <= 1024 in the y = x W^T layout (greedy skip decoding: M = batch).  Latency-, not
 // MFMA-bound: a 32x32 output tile per workgroup, K split over the 4 wavefronts, and every wavefront loads
 // its fragments straight from global memory into registers in bursts of 64 k (no LDS staging, no barrier
 // in the K loop: one memory round trip per burst instead of one per K-tile), then the four partial
@@ -414,7 +471,7 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_skinny_kernel(const SkinnyL
 static bool skinny_ok(const nast_gemm_desc* descs, int count) {
   for (int i = 0; i < count; ++i) {
     const nast_gemm_desc& D = descs[i];
-    if (D.M > 128 || D.transA != 0 || D.transB == 0 || D.nsrc != 1 || D.relu_src || D.colsum || (D.flags & NAST_GEMM_ATOMIC)) return false;
+    if (D.M > 1024 || D.transA != 0 || D.transB == 0 || D.nsrc != 1 || D.relu_src || D.colsum || (D.flags & NAST_GEMM_ATOMIC)) return false;
     if (D.ln_gamma && (D.K > 256 || !D.ln_beta)) return false;
     if ((D.lda & 3) || (D.ldb & 3) || (reinterpret_cast<uintptr_t>(D.A[0]) & 15) || (reinterpret_cast<uintptr_t>(D.B[0]) & 15)) return false;
   }
@@ -456,6 +513,12 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
   int tiles = 0;
   for (int i = 0; i < count; ++i) {
     P.d[i] = descs[i];
+    {
+      const nast_gemm_desc& D = descs[i];
+      auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+      if ((D.ldc & 3) == 0 && (D.N & 3) == 0 && al(D.C) && al(D.bias) && al(D.residual) && al(D.relu_src)) P.d[i].flags |= NAST_GEMM_VEC_C;
+      else P.d[i].flags &= ~NAST_GEMM_VEC_C;
+    }
     P.tiles_m[i] = (descs[i].M + BM - 1) / BM;
     P.tiles_n[i] = (descs[i].N + BN - 1) / BN;
     tiles += P.tiles_m[i] * P.tiles_n[i];
@@ -551,12 +614,12 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
   }
   const bool skinny = skinny_ok(descs, count);
   for (int i = 0; i < count; ++i)
-    NAST_REQUIRE(descs[i].ln_gamma == nullptr || skinny, "nast_gemm_f32[%d]: fused LayerNorm needs the small-M path (M<=128, K<=256, x W^T)", i);
+    NAST_REQUIRE(descs[i].ln_gamma == nullptr || skinny, "nast_gemm_f32[%d]: fused LayerNorm needs the small-M path (M<=1024, K<=256, x W^T)", i);
   int tilesL = 0;
-  plan_and_launch<128, 128, 16>(descs, count, stream, true, &tilesL);
+  plan_and_launch<128, 128, NAST_BK128>(descs, count, stream, true, &tilesL);
   nast_prof_before(1, stream);
   if (skinny) launch_skinny(descs, count, stream);
-  else if (tilesL >= 384) plan_and_launch<128, 128, 16>(descs, count, stream, false, nullptr);
+  else if (tilesL >= 384) plan_and_launch<128, 128, NAST_BK128>(descs, count, stream, false, nullptr);
   else plan_and_launch<64, 64, 32>(descs, count, stream, false, nullptr);
   nast_prof_after(1, stream, flops);
   NAST_CHECK_LAUNCH("nast_gemm_f32");
