@@ -203,20 +203,30 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
 #pragma unroll
         for (int b = 0; b < NT; ++b) fb[n][b] = frag_read<BN, BK, BKC>(Bs, wn * WTN + b * 32 + li, g + 1, lh);
       }
+      if (g == NG / 2 && step + 1 < steps) {
+        // the next tile's LDS image is written in the middle of this tile's MFMA stream (its buffer was last
+        // read before the previous barrier), so the stores issue in the shadow of the matrix pipe
+        float* An = smem + (cur ^ 1) * (GA::SZ + GB::SZ);
+        tile_store<BM, BK, AKC>(An, ra);
+        tile_store<BN, BK, BKC>(An + GA::SZ, rb);
+      }
+      // k-step outermost: consecutive MFMAs go to different accumulators (dependent distance MT*NT)
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].x, fb[c][b].x, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].y, fb[c][b].y, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].z, fb[c][b].z, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].w, fb[c][b].w, acc[a][b], 0, 0, 0);
-        }
-    }
-    if (step + 1 < steps) {
-      float* An = smem + (cur ^ 1) * (GA::SZ + GB::SZ);
-      tile_store<BM, BK, AKC>(An, ra);
-      tile_store<BN, BK, BKC>(An + GA::SZ, rb);
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].x, fb[c][b].x, acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].y, fb[c][b].y, acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].z, fb[c][b].z, acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].w, fb[c][b].w, acc[a][b], 0, 0, 0);
     }
     __syncthreads();
   }
