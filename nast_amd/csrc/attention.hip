@@ -228,6 +228,14 @@ static int check_common(const char* name, int B, int h, int nq, int nk, int dk, 
 
 #define LDS_LIMIT (160 * 1024)
 
+// matrix-core kernels for nq, nk <= 64 (attention_mfma.hip); return 1 when the shape is outside their limits
+int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, float* out, float* lse, int B, int h, int nq,
+                      int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
+                      int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s);
+int nast_mha_bwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, const float* dout, const float* lse, float* dq,
+                      float* dk_, float* dv, int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs,
+                      int64_t k_bs, int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s);
+
 template <int DK>
 static int launch_fwd(const float* q, const float* k, const float* v, const uint8_t* mask, float* out, float* lse, int B,
                       int h, int nq, int nk, int ldq, int ldk, int ldv, int ldo, int64_t qb, int64_t kb, int64_t vb, int64_t ob,
@@ -280,6 +288,11 @@ extern "C" int nast_mha_fwd_f32(const float* q, const float* k, const float* v, 
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(q && k && v && out && lse, "nast_mha_fwd_f32: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
+  if (((q_bs | k_bs | v_bs | o_bs) & 3) == 0 &&
+      nast_mha_fwd_mfma(q, k, v, mask, out, lse, B, h, nq, nk, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s) == 0) {
+    NAST_CHECK_LAUNCH("nast_mha_fwd_f32(mfma)");
+    return NAST_OK;
+  }
   switch (dk) {
     case 8: return launch_fwd<8>(q, k, v, mask, out, lse, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
     case 16: return launch_fwd<16>(q, k, v, mask, out, lse, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
@@ -298,6 +311,11 @@ extern "C" int nast_mha_bwd_f32(const float* q, const float* k, const float* v, 
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(q && k && v && dout && lse && dq && dk_ && dv, "nast_mha_bwd_f32: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
+  if (((q_bs | k_bs | v_bs | o_bs) & 3) == 0 &&
+      nast_mha_bwd_mfma(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s) == 0) {
+    NAST_CHECK_LAUNCH("nast_mha_bwd_f32(mfma)");
+    return NAST_OK;
+  }
   switch (dk) {
     case 8: return launch_bwd<8>(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);
     case 16: return launch_bwd<16>(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s);

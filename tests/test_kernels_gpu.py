@@ -120,7 +120,8 @@ def ref_attention(q, k, v, mask, h):
 
 @pytest.mark.parametrize("B,nq,nk,h,dk,kind", [(3, 7, 9, 4, 8, "pad"), (4, 17, 17, 4, 64, "pad"), (2, 33, 33, 4, 64, "causal"),
                                                 (2, 33, 34, 4, 64, "pad"), (2, 70, 70, 2, 64, "causal"), (1, 130, 130, 2, 64, "pad"),
-                                                (2, 1, 12, 4, 16, "none"), (2, 9, 9, 2, 32, "causal")])
+                                                (2, 1, 12, 4, 16, "none"), (2, 9, 9, 2, 32, "causal"),
+                                                (2, 40, 20, 4, 16, "pad"), (3, 64, 64, 2, 64, "pad"), (2, 20, 50, 2, 8, "pad"), (2, 48, 49, 2, 32, "none")])
 def test_attention(ops, B, nq, nk, h, dk, kind):
     g = torch.Generator().manual_seed(B * 100 + nq)
     D = h * dk
