@@ -5,9 +5,11 @@ A "step" is one `Seq2seq.f_step` as the reference defines it (seq2seq.py:416-543
 generator forward passes (self-reconstruction, transfer with greedy skip decoding, cycle reconstruction from
 Gumbel-softmax soft tokens), one discriminator forward, two backward passes, global-norm clip and Adam.
 
-Workload (BASELINE.json configs[2]): learnable alignment, GYAFC-shaped synthetic batch (len <= 32, vocab 9600,
-d=256, h=4, 4 layers), 64 sentences per GPU, fp32 (the reference's dtype), use_inference_z=True.
-Weak scaling: every rank holds its own 64 sentences; gradients are averaged with bucketed RCCL all-reduce.
+Workload (BASELINE.json configs[2]/[3]): learnable alignment, GYAFC-shaped synthetic batch (len <= 32, vocab 9600,
+d=256, h=4, 4 layers), 512 sentences per GPU (the per-GPU batch configs[3] names for the 2/4/8-GPU runs, used at
+N=1 as well so that the scaling is weak: fixed work per GPU), fp32 (the reference's dtype), use_inference_z=True.
+Every rank holds its own 512 sentences; gradients are averaged with bucketed RCCL all-reduce.  At N=1 the line
+also carries "also.bs64" = the same step at 64 sentences (the reference's batch size).
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -78,6 +80,7 @@ def build_model(cfg, device):
 
 
 def cpu_baseline(model, cfg, B, steps=2):
+    B = min(B, 128)      # bounded sample: CPU throughput of this path is flat in the batch size
     """The CPU oracle (oracle/nast_oracle.py, pinned against the reference by the golden fixtures) timed on this
     box's host cores on a bounded sample of the same workload."""
     from oracle import nast_oracle as O
@@ -106,7 +109,7 @@ def cpu_baseline(model, cfg, B, steps=2):
             times.append(t2 - t1)      # the shape probe (t1 - t0) is harness overhead, not part of the step
     sps = B / (sum(times) / len(times))
     return {"value": round(sps, 2), "unit": "sentences/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} f_step of the same workload (B={B}) after 1 warm-up, torch CPU fp32, {threads} threads"}
+            "sample": f"{steps} f_step of the same workload on a {B}-sentence sample after 1 warm-up, torch CPU fp32, {threads} threads"}
 
 
 def main():
@@ -114,11 +117,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--batch-per-gpu", type=int, default=512)
     ap.add_argument("--alignment", default="learnable", choices=["learnable", "simple"])
     ap.add_argument("--max-length", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,6 +164,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    also = None
+    if world == 1 and B > 64 and not a.no_also:
+        # the same step at the reference's batch size (64 sentences)
+        small = [synth_incoming(64, L, cfg["V"], 5000 + i, "cuda") for i in range(4)]
+        for i in range(3):
+            model.f_step(small[i % 4], 1.0, use_inference_z=True)
+        torch.cuda.synchronize()
+        n_small = min(a.steps, 10)
+        t1 = time.perf_counter()
+        for i in range(n_small):
+            model.f_step(small[i % 4], 1.0, use_inference_z=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / n_small
+        also = {"bs64": {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_small}}
+
     roofline = None
     if rank == 0 and not a.no_roofline:
         # second pass over the same steps with HIP-event timing armed around every launch of the dominant
@@ -189,7 +208,7 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"NAST-StyTrans f_step, {a.alignment} alignment, len<={L}, vocab 9600, d=256, h=4, 4 layers, "
-                                   f"{B} sentences/GPU (BASELINE configs[{2 if learnable else 1}])",
+                                   f"{B} sentences/GPU (BASELINE configs[{'2] at the per-GPU batch of configs[3' if learnable else '1'}])",
                        "global_batch": B * world, "max_length": L, "parallelism": f"dp{world}"},
         }
         if key in GFLOP_PER_SENTENCE:
@@ -198,6 +217,8 @@ def main():
             out["step_frac_of_fp32_mfma_peak"] = round(tf / (PEAK_FP32_MFMA_TFLOPS * world), 4)
         if roofline:
             out["roofline"] = roofline
+        if also:
+            out["also"] = also
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, cfg, B)
         print(json.dumps(out), flush=True)
