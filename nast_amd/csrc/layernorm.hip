@@ -1,5 +1,7 @@
 // LayerNorm forward / backward, one 64-wide wavefront per row (d <= 1024 -> <= 16 values per lane,
 // kept in registers; HBM-bound: 8d bytes/row forward).
+#include <initializer_list>
+
 #include "common.h"
 
 #define LN_MAX_PER_LANE 16
@@ -108,6 +110,130 @@ __global__ __launch_bounds__(256) void nast_ln_bwd_kernel(const float* __restric
   }
 }
 
+
+// ---- 16-byte variants (d % 4 == 0, identity or mapped rows): lane owns columns 4*lane + 256*i .. +3 -----------
+template <int NV>
+__global__ __launch_bounds__(256) void nast_ln_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ y,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, int rows_out,
+                                                              int d, float eps, int grp, int grp_stride, int grp_off) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows_out) return;
+  const float* xr = x + ln_in_row(r, grp, grp_stride, grp_off) * d;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * lane + 256 * i;
+    v[i] = c < d ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mu = wave_sum(s) / d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < d) {
+      const float a = v[i].x - mu, b = v[i].y - mu, e = v[i].z - mu, f = v[i].w - mu;
+      q += (a * a + b * b) + (e * e + f * f);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / d + eps);
+  float* yr = y + (int64_t)r * d;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < d) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+      float4 o;
+      o.x = (v[i].x - mu) * rs * g.x + b.x; o.y = (v[i].y - mu) * rs * g.y + b.y;
+      o.z = (v[i].z - mu) * rs * g.z + b.z; o.w = (v[i].w - mu) * rs * g.w + b.w;
+      *reinterpret_cast<float4*>(yr + c) = o;
+    }
+  }
+  if (lane == 0) {
+    mean[r] = mu;
+    rstd[r] = rs;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void nast_ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* __restrict__ dx,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              const float* __restrict__ dx_add, int rows_out, int d, int grp,
+                                                              int grp_stride, int grp_off) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][4][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 gam[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * lane + 256 * i;
+    gam[i] = c < d ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int r = blockIdx.x * 4 + wave; r < rows_out; r += gridDim.x * 4) {
+    const int64_t ir = ln_in_row(r, grp, grp_stride, grp_off);
+    const float* xr = x + ir * d;
+    const float* gr = dy + (int64_t)r * d;
+    const float mu = mean[r], rs = rstd[r];
+    float4 xh[NV], g[NV], ad[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * lane + 256 * i;
+      const bool ok = c < d;
+      const float4 dyv = ok ? *reinterpret_cast<const float4*>(gr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 xv = ok ? *reinterpret_cast<const float4*>(xr + c) : make_float4(mu, mu, mu, mu);
+      ad[i] = (ok && dx_add) ? *reinterpret_cast<const float4*>(dx_add + ir * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+      g[i].x = dyv.x * gam[i].x; g[i].y = dyv.y * gam[i].y; g[i].z = dyv.z * gam[i].z; g[i].w = dyv.w * gam[i].w;
+      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+      ag[i].x += dyv.x * xh[i].x; ag[i].y += dyv.y * xh[i].y; ag[i].z += dyv.z * xh[i].z; ag[i].w += dyv.w * xh[i].w;
+      ab[i].x += dyv.x; ab[i].y += dyv.y; ab[i].z += dyv.z; ab[i].w += dyv.w;
+    }
+    s1 = wave_sum(s1) / d;
+    s2 = wave_sum(s2) / d;
+    float* dxr = dx + ir * d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * lane + 256 * i;
+      if (c < d) {
+        float4 o;
+        o.x = rs * (g[i].x - s1 - xh[i].x * s2) + ad[i].x; o.y = rs * (g[i].y - s1 - xh[i].y * s2) + ad[i].y;
+        o.z = rs * (g[i].z - s1 - xh[i].z * s2) + ad[i].z; o.w = rs * (g[i].w - s1 - xh[i].w * s2) + ad[i].w;
+        *reinterpret_cast<float4*>(dxr + c) = o;
+      }
+    }
+  }
+  float* rg = red;
+  float* rb = red + 4 * d;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < d) {
+      *reinterpret_cast<float4*>(rg + wave * d + c) = ag[i];
+      *reinterpret_cast<float4*>(rb + wave * d + c) = ab[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    atomicAdd(dgamma + c, rg[c] + rg[d + c] + rg[2 * d + c] + rg[3 * d + c]);
+    atomicAdd(dbeta + c, rb[c] + rb[d + c] + rb[2 * d + c] + rb[3 * d + c]);
+  }
+}
+
+static bool ln_vec_ok(int d, std::initializer_list<const void*> ptrs) {
+  if (d & 3) return false;
+  for (const void* p : ptrs)
+    if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+  return true;
+}
+
 extern "C" int nast_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                       float* rstd, int rows_out, int d, float eps, int grp, int grp_stride,
                                       int grp_off, void* stream) {
@@ -115,8 +241,16 @@ extern "C" int nast_layernorm_fwd_f32(const float* x, const float* gamma, const 
   NAST_REQUIRE(rows_out >= 0, "nast_layernorm_fwd_f32: rows_out < 0");
   if (rows_out == 0) return NAST_OK;
   NAST_REQUIRE(x && gamma && beta && y && mean && rstd, "nast_layernorm_fwd_f32: NULL pointer");
-  hipLaunchKernelGGL(nast_ln_fwd_kernel, dim3((rows_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                     mean, rstd, rows_out, d, eps, grp, grp_stride, grp_off);
+  const dim3 grid((rows_out + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (ln_vec_ok(d, {x, gamma, beta, y}) && d <= 256)
+    hipLaunchKernelGGL(nast_ln_fwd_vec_kernel<1>, grid, block, 0, st, x, gamma, beta, y, mean, rstd, rows_out, d, eps, grp, grp_stride, grp_off);
+  else if (ln_vec_ok(d, {x, gamma, beta, y}) && d <= 512)
+    hipLaunchKernelGGL(nast_ln_fwd_vec_kernel<2>, grid, block, 0, st, x, gamma, beta, y, mean, rstd, rows_out, d, eps, grp, grp_stride, grp_off);
+  else if (ln_vec_ok(d, {x, gamma, beta, y}))
+    hipLaunchKernelGGL(nast_ln_fwd_vec_kernel<4>, grid, block, 0, st, x, gamma, beta, y, mean, rstd, rows_out, d, eps, grp, grp_stride, grp_off);
+  else
+    hipLaunchKernelGGL(nast_ln_fwd_kernel, grid, block, 0, st, x, gamma, beta, y, mean, rstd, rows_out, d, eps, grp, grp_stride, grp_off);
   NAST_CHECK_LAUNCH("nast_layernorm_fwd_f32");
   return NAST_OK;
 }
@@ -138,9 +272,18 @@ extern "C" int nast_layernorm_bwd_f32(const float* dy, const float* x, const flo
   }
   if (rows_out == 0) return NAST_OK;
   int blocks = (rows_out + 3) / 4;
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(nast_ln_bwd_kernel, dim3(blocks), dim3(256), 2 * 4 * d * sizeof(float), s, dy, x, gamma, mean, rstd,
-                     dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+  if (blocks > 2048) blocks = 2048;     // 8 workgroups per CU keep enough rows in flight; <= 2048 atomics per column
+  const size_t lds = 2 * 4 * d * sizeof(float);
+  const bool vec = ln_vec_ok(d, {dy, x, gamma, dx, dx_add});
+  if (vec && d <= 256)
+    hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<1>, dim3(blocks), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+  else if (vec && d <= 512)
+    hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<2>, dim3(blocks), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+  else if (vec)
+    hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<4>, dim3(blocks), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+  else
+    hipLaunchKernelGGL(nast_ln_bwd_kernel, dim3(blocks < 512 ? blocks : 512), dim3(256), lds, s, dy, x, gamma, mean, rstd,
+                       dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
   NAST_CHECK_LAUNCH("nast_layernorm_bwd_f32");
   return NAST_OK;
 }

@@ -8,12 +8,16 @@ the parameter group being stepped:
     armed only for the last one, so each gradient is reduced once per step, after its final accumulation;
   * gradients are packed into flat buckets (default 16 MiB: F's 62 MB -> 4 buckets, large enough to run at
     link bandwidth on the 7x xGMI links, small enough that the first bucket leaves while backward still runs)
-    in the order their autograd hooks fire, and each bucket's all-reduce is launched asynchronously from the
-    hook of its last gradient -> communication overlaps the rest of backward;
-  * parameters that never receive a gradient (sos_token, transformer.py:41; all of F during d_step) are
-    simply never seen by a hook and take no part;
-  * the bucket plan is learnt on the first armed step (which reduces after backward, un-overlapped) and must
-    be identical on all ranks -- it is, because every rank runs the same graph.
+    in the order they become final, and each bucket's all-reduce is launched asynchronously as soon as its last
+    gradient is final -> communication overlaps the rest of backward;
+  * a gradient is "final" after its last contribution of the armed backward.  Contributions are either
+    autograd's AccumulateGrad (post-accumulate hook) or the in-place accumulation of the HIP backward
+    kernels (nast_amd.ops.grad_listener); a parameter can receive several (the token embedding is used by the
+    gather, the soft-token GEMM and the eos/unk rows), so the number per parameter is learnt on the first
+    armed step of each step variant (`tag`) -- that step reduces after backward, un-overlapped;
+  * if a later step produces a contribution after its bucket has left (the graph changed), the step falls
+    back to a full synchronous reduce and the plan is re-learnt: never a stale gradient;
+  * parameters that never receive a gradient (sos_token, transformer.py:41; all of F during d_step) take no part.
 
 Local losses are divided by the LOCAL batch size (as the reference divides by its batch size); averaging
 the gradients over ranks therefore equals the single-GPU gradient on the concatenated batch when all ranks
@@ -22,110 +26,158 @@ hold equally many sentences.
 import torch
 import torch.distributed as dist
 
+_reducers = []
+
+
+def _listener(p):
+    for r in _reducers:
+        r._notify_param(p)
+
+
+class _Plan:
+    def __init__(self, counts, buckets):
+        self.counts = counts                    # param index -> contributions per armed backward
+        self.buckets = buckets                  # list of lists of param indices
+        self.bucket_of = {i: b for b, idxs in enumerate(buckets) for i in idxs}
+        self.flat = None
+
 
 class GradReducer:
     def __init__(self, params, bucket_bytes=16 << 20, group=None):
         self.params = [p for p in params if p.requires_grad]
+        self.index = {id(p): i for i, p in enumerate(self.params)}
         self.group = group
         self.bucket_bytes = bucket_bytes
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.armed = False
-        self.plan = None          # list of lists of param indices
-        self.bucket_of = {}
-        self.flat = []            # one flat buffer per bucket
+        self.plans = {}
+        self.plan = None
+        self.tag = None
         self._fired = []
-        self._count = []
-        self._work = []
-        self._launched = []
         if self.enabled:
+            from . import ops
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
+            _reducers.append(self)
+            ops.grad_listener = _listener
 
     def _make_hook(self, i):
         def hook(_param):
-            if not self.armed:
-                return
-            self._fired.append(i)
-            if self.plan is not None and i in self.bucket_of:
-                b = self.bucket_of[i]
-                self._count[b] += 1
-                if self._count[b] == len(self.plan[b]):
-                    self._launch(b)
+            self._notify(i)
         return hook
 
-    def arm(self):
+    def _notify_param(self, p):
+        i = self.index.get(id(p))
+        if i is not None:
+            self._notify(i)
+
+    def _notify(self, i):
+        if not self.armed:
+            return
+        self._fired.append(i)
+        plan = self.plan
+        if plan is None:
+            return
+        if i not in plan.bucket_of:
+            self._dirty = True
+            return
+        self._seen[i] = self._seen.get(i, 0) + 1
+        b = plan.bucket_of[i]
+        if self._launched[b]:
+            self._dirty = True                  # a contribution arrived after the bucket left
+        elif self._seen[i] == plan.counts[i]:
+            self._ready[b] += 1
+            if self._ready[b] == len(plan.buckets[b]):
+                self._launch(b)
+
+    def arm(self, tag="default"):
         """Call right before the backward pass whose gradients are final for this step."""
         if not self.enabled:
             return
         self.armed = True
+        self.tag = tag
+        self.plan = self.plans.get(tag)
         self._fired = []
+        self._dirty = False
+        self._seen = {}
         if self.plan is not None:
-            self._count = [0] * len(self.plan)
-            self._launched = [False] * len(self.plan)
-            self._work = [None] * len(self.plan)
+            n = len(self.plan.buckets)
+            self._ready = [0] * n
+            self._launched = [False] * n
+            self._work = [None] * n
 
-    def _build_plan(self, order):
-        plan, cur, size = [], [], 0
+    def _build_plan(self):
+        counts, last = {}, {}
+        for pos, i in enumerate(self._fired):
+            counts[i] = counts.get(i, 0) + 1
+            last[i] = pos
+        order = sorted(last, key=last.get)      # by the time the gradient became final
+        buckets, cur, size = [], [], 0
         for i in order:
             n = self.params[i].numel() * self.params[i].element_size()
             if cur and size + n > self.bucket_bytes:
-                plan.append(cur)
+                buckets.append(cur)
                 cur, size = [], 0
             cur.append(i)
             size += n
         if cur:
-            plan.append(cur)
-        self.plan = plan
-        self.bucket_of = {i: b for b, idxs in enumerate(plan) for i in idxs}
-        self.flat = [torch.empty(sum(self.params[i].numel() for i in idxs), dtype=self.params[idxs[0]].dtype,
-                                 device=self.params[idxs[0]].device) for idxs in plan]
-        self._count = [0] * len(plan)
-        self._launched = [False] * len(plan)
-        self._work = [None] * len(plan)
+            buckets.append(cur)
+        plan = _Plan(counts, buckets)
+        plan.flat = [torch.empty(sum(self.params[i].numel() for i in idxs), dtype=self.params[idxs[0]].dtype,
+                                 device=self.params[idxs[0]].device) for idxs in buckets]
+        return plan
 
-    def _views(self, b):
+    def _views(self, plan, b):
         out, off = [], 0
-        for i in self.plan[b]:
+        for i in plan.buckets[b]:
             n = self.params[i].numel()
-            out.append(self.flat[b][off:off + n].view_as(self.params[i]))
+            out.append(plan.flat[b][off:off + n].view_as(self.params[i]))
             off += n
         return out
 
     def _launch(self, b):
-        grads = [self.params[i].grad for i in self.plan[b]]
-        views = self._views(b)
+        plan = self.plan
+        grads = [self.params[i].grad for i in plan.buckets[b]]
+        views = self._views(plan, b)
         for v, g in zip(views, grads):
             if g is None:
                 v.zero_()
         pairs = [(v, g) for v, g in zip(views, grads) if g is not None]
         if pairs:
             torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
-        self._work[b] = dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._work[b] = dist.all_reduce(plan.flat[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._launched[b] = True
+
+    def _write_back(self, b):
+        plan = self.plan
+        views = self._views(plan, b)
+        pairs = [(self.params[i].grad, v) for i, v in zip(plan.buckets[b], views) if self.params[i].grad is not None]
+        if pairs:
+            torch._foreach_mul_([v for _, v in pairs], 1.0 / self.world)
+            torch._foreach_copy_([g for g, _ in pairs], [v for _, v in pairs])
 
     def finish(self):
         """Call after that backward: waits for the buckets, writes the averaged gradients back."""
         if not self.enabled:
             return
         self.armed = False
+        if self.plan is not None and self._dirty:
+            # the graph differs from the learnt one: drain what was sent, then redo everything synchronously
+            for b, w in enumerate(self._work):
+                if w is not None:
+                    w.wait()
+            self.plan = None
         if self.plan is None:
-            seen, order = set(), []
-            for i in self._fired:
-                if i not in seen:
-                    seen.add(i)
-                    order.append(i)
-            if not order:
+            if not self._fired:
                 return
-            self._build_plan(order)
-        for b in range(len(self.plan)):
+            self.plan = self.plans[self.tag] = self._build_plan()
+            n = len(self.plan.buckets)
+            self._launched = [False] * n
+            self._work = [None] * n
+        for b in range(len(self.plan.buckets)):
             if not self._launched[b]:
                 self._launch(b)
-        inv = 1.0 / self.world
-        for b in range(len(self.plan)):
+        for b in range(len(self.plan.buckets)):
             self._work[b].wait()
-            views = self._views(b)
-            pairs = [(self.params[i].grad, v) for i, v in zip(self.plan[b], views) if self.params[i].grad is not None]
-            if pairs:
-                torch._foreach_mul_([v for _, v in pairs], inv)
-                torch._foreach_copy_([g for g, _ in pairs], [v for _, v in pairs])
+            self._write_back(b)

@@ -92,9 +92,19 @@ def d_dgrad(dy2_list, W_list, dx2, relu_src=None):
 
 def d_wgrad(dy2, x2, dW, db=None):
     """dW[N,K] += dy[M,N]^T @ x[M,K]  (atomic, split-K), db[N] += colsum(dy)"""
+    assert dW is not None
     M, N = dy2.shape
     K = x2.shape[1]
     return desc(dy2, x2, dW, N, K, M, N, K, K, 1, 0, colsum=db, flags=GEMM_ATOMIC)
+
+
+def wgrad_descs(dy2, x2, dW, db):
+    """[] when the weight is frozen (a frozen weight with a live bias falls back to a column sum)."""
+    if dW is not None:
+        return [d_wgrad(dy2, x2, dW, db)]
+    if db is not None:
+        db += dy2.sum(0)
+    return []
 
 
 def zeros_like_many(tensors):
@@ -107,6 +117,57 @@ def zeros_like_many(tensors):
         tot += (n + 3) // 4 * 4
     flat = torch.zeros(tot, device=tensors[0].device, dtype=F32)
     return [flat[o:o + n].view(t.shape) for o, n, t in zip(offs, sizes, tensors)]
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter gradients are accumulated IN PLACE
+# ------------------------------------------------------------------------------------------------
+# The weight-gradient GEMMs, LayerNorm / embedding backward kernels accumulate with fp32 atomics, so for a leaf
+# parameter they add straight into `param.grad` (created zero-filled on first use) and the autograd Function
+# returns None for it: no per-parameter zero-fill, no `grad += new` kernel for the second backward of f_step
+# (seq2seq.py:464, :530) and no index_put through a [V, d] temporary for single embedding rows.
+# `grad_listener` (set by nast_amd.ddp.GradReducer) is told about every in-place contribution, because
+# autograd's post-accumulate hooks do not fire for gradients that never pass through AccumulateGrad.
+INPLACE_GRADS = True
+grad_listener = None
+
+
+def _sink(p):
+    if not INPLACE_GRADS or p is None or not p.is_leaf:
+        return None
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def live(*params):
+    """Record at FORWARD time which parameters take a gradient (frozen ones -> None), like ctx.needs_input_grad."""
+    return tuple(p if (p is not None and p.requires_grad) else None for p in params)
+
+
+def grad_buffers(params):
+    """For each entry of `params` (tensor or None): (buffer to accumulate into or None when no gradient is needed,
+    value to return from backward).  Leaves get their .grad, everything else a slice of one zero-filled buffer."""
+    bufs, rets, fresh = [None] * len(params), [None] * len(params), []
+    for i, p in enumerate(params):
+        if p is None:
+            continue
+        sk = _sink(p)
+        if sk is not None:
+            bufs[i] = sk
+        else:
+            fresh.append(i)
+    if fresh:
+        for i, z in zip(fresh, zeros_like_many([params[i] for i in fresh])):
+            bufs[i] = rets[i] = z
+    return bufs, rets
+
+
+def grads_written(params):
+    if grad_listener is not None:
+        for p in params:
+            if p is not None and p.is_leaf and INPLACE_GRADS:
+                grad_listener(p)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -193,29 +254,37 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, W, b, residual, relu):
         _chk(x, W, b, residual)
         x2 = _c(x).view(-1, x.shape[-1])
+        W0 = W
         W = _c(W)
         y2 = torch.empty(x2.shape[0], W.shape[0], device=x.device, dtype=F32)
         r2 = _c(residual).view(-1, W.shape[0]) if residual is not None else None
         gemm([d_fwd(x2, W, y2, bias=b, residual=r2, relu=relu)])
         ctx.save_for_backward(x2, W, y2 if relu else None)
-        ctx.has_b, ctx.has_res, ctx.relu, ctx.xshape = b is not None, residual is not None, relu, x.shape
+        ctx.params = live(W0, b)
+        ctx.has_res, ctx.relu, ctx.xshape = residual is not None, relu, x.shape
         return y2.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, W, y2 = ctx.saved_tensors
+        pW, pb = ctx.params
         dy2 = _c(dy).view(-1, W.shape[0])
         if ctx.relu:
             dy2 = dy2 * (y2 > 0)   # only on the fine-grained path; the fused FFN masks inside the dgrad epilogue
-        dW, db = zeros_like_many([W, W.new_empty(W.shape[0])])
-        descs = [d_wgrad(dy2, x2, dW, db if ctx.has_b else None)]
+        (dW, db), (rW, rb) = grad_buffers([pW, pb])
+        descs = []
+        if dW is not None:
+            descs.append(d_wgrad(dy2, x2, dW, db))
+        elif db is not None:
+            db += dy2.sum(0)
         dx2 = None
         if ctx.needs_input_grad[0]:
             dx2 = torch.empty_like(x2)
             descs.append(d_dgrad([dy2], [W], dx2))
-        gemm(descs)
-        return (dx2.view(ctx.xshape) if dx2 is not None else None, dW, db if ctx.has_b else None,
-                dy if ctx.has_res else None, None)
+        if descs:
+            gemm(descs)
+        grads_written([pW, pb])
+        return (dx2.view(ctx.xshape) if dx2 is not None else None, rW, rb, dy if ctx.has_res else None, None)
 
 
 def linear(x, W, b=None, residual=None, relu=False):
@@ -229,12 +298,14 @@ class MatmulNNFn(torch.autograd.Function):
     def forward(ctx, x, E):
         _chk(x, E)
         x2 = _c(x).view(-1, x.shape[-1])
+        E0 = E
         E = _c(E)
         M, K = x2.shape
         N = E.shape[1]
         y2 = torch.empty(M, N, device=x.device, dtype=F32)
         gemm([desc(x2, E, y2, M, N, K, K, N, N, 0, 0)])
         ctx.save_for_backward(x2, E)
+        ctx.params = live(E0)
         ctx.xshape = x.shape
         return y2.view(*x.shape[:-1], N)
 
@@ -244,15 +315,17 @@ class MatmulNNFn(torch.autograd.Function):
         M, K = x2.shape
         N = E.shape[1]
         dy2 = _c(dy).view(M, N)
-        descs, dx2, dE = [], None, None
+        descs, dx2 = [], None
         if ctx.needs_input_grad[0]:
             dx2 = torch.empty_like(x2)                       # dX = dY E^T
             descs.append(desc(dy2, E, dx2, M, K, N, N, N, K, 0, 1))
-        if ctx.needs_input_grad[1]:
-            dE = torch.zeros_like(E)                         # dE = X^T dY
+        (dE,), (rE,) = grad_buffers(list(ctx.params))
+        if dE is not None:                                   # dE += X^T dY
             descs.append(desc(x2, dy2, dE, K, N, M, K, N, N, 1, 0, flags=GEMM_ATOMIC))
-        gemm(descs)
-        return (dx2.view(ctx.xshape) if dx2 is not None else None), dE
+        if descs:
+            gemm(descs)
+        grads_written(ctx.params)
+        return (dx2.view(ctx.xshape) if dx2 is not None else None), rE
 
 
 def matmul_nn(x, E):
@@ -268,6 +341,7 @@ class LayerNormFn(torch.autograd.Function):
         x2 = _c(x).view(-1, x.shape[-1])
         y, mean, rstd = ln_fwd(x2, gamma, beta, rows_out if grp else None, grp, grp_stride, grp_off)
         ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.params = live(gamma, beta)
         ctx.map = (grp, grp_stride, grp_off)
         ctx.xshape = x.shape
         return y if grp else y.view(x.shape)
@@ -275,10 +349,20 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, gamma, mean, rstd = ctx.saved_tensors
-        dg, db = zeros_like_many([gamma, gamma])
+        (dg, db), (rg, rb) = ln_param_buffers(ctx.params[0], ctx.params[1], gamma)
         dy2 = _c(dy).view(-1, x2.shape[1])
         dx = ln_bwd(dy2, x2, gamma, mean, rstd, dg, db, None, *ctx.map)
-        return dx.view(ctx.xshape), dg, db, None, None, None, None
+        grads_written(ctx.params)
+        return dx.view(ctx.xshape), rg, rb, None, None, None, None
+
+
+def ln_param_buffers(gamma, beta, like):
+    """The LayerNorm backward kernel always accumulates both parameter gradients: frozen parameters get scratch."""
+    bufs, rets = grad_buffers([gamma, beta])
+    for i in range(2):
+        if bufs[i] is None:
+            bufs[i] = torch.zeros_like(like)
+    return bufs, rets
 
 
 def layer_norm(x, gamma, beta):
@@ -340,6 +424,7 @@ class AttnSublayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2, z, mean, rstd, kv2 if not self_attn else None, q, k, v, a, lse,
                               ln_w, Wq, Wk, Wv, Wo)
         ctx.mask, ctx.h, ctx.self_attn, ctx.shape, ctx.nk = mask, h, self_attn, (B, nq, d), nk
+        ctx.params = live(ln_w, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo)
         return y.view(B, nq, d)
 
     @staticmethod
@@ -350,14 +435,14 @@ class AttnSublayerFn(torch.autograd.Function):
         if kv2 is None:
             kv2 = z
         dy2 = _c(dy).view(-1, d)
-        dlnw, dlnb, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo = zeros_like_many(
-            [ln_w, ln_w, Wq, ln_w, Wk, ln_w, Wv, ln_w, Wo, ln_w])
+        (_, _, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo), rets = grad_buffers(list(ctx.params))
+        (dlnw, dlnb), _ = ln_param_buffers(ctx.params[0], ctx.params[1], ln_w)
         da = torch.empty_like(a).view(-1, d)
-        gemm([d_dgrad([dy2], [Wo], da), d_wgrad(dy2, a.view(-1, d), dWo, dbo)])
+        gemm([d_dgrad([dy2], [Wo], da)] + wgrad_descs(dy2, a.view(-1, d), dWo, dbo))
         dq, dk_, dv = mha_bwd(q.view(B, nq, d), k.view(B, nk, d), v.view(B, nk, d), ctx.mask, ctx.h, a, da.view(B, nq, d), lse)
         dq2, dk2, dv2 = dq.view(-1, d), dk_.view(-1, d), dv.view(-1, d)
         dz = torch.empty_like(z)
-        descs = [d_wgrad(dq2, z, dWq, dbq), d_wgrad(dk2, kv2, dWk, dbk), d_wgrad(dv2, kv2, dWv, dbv)]
+        descs = wgrad_descs(dq2, z, dWq, dbq) + wgrad_descs(dk2, kv2, dWk, dbk) + wgrad_descs(dv2, kv2, dWv, dbv)
         dkv = None
         if ctx.self_attn:
             descs.append(d_dgrad([dq2, dk2, dv2], [Wq, Wk, Wv], dz))
@@ -368,8 +453,8 @@ class AttnSublayerFn(torch.autograd.Function):
                 descs.append(d_dgrad([dk2, dv2], [Wk, Wv], dkv))
         gemm(descs)
         dx = ln_bwd(dz, x2, ln_w, mean, rstd, dlnw, dlnb, dx_add=dy2)
-        return (dx.view(B, nq, d), dkv.view(B, nk, d) if dkv is not None else None, None, None,
-                dlnw, dlnb, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo)
+        grads_written(ctx.params)
+        return (dx.view(B, nq, d), dkv.view(B, nk, d) if dkv is not None else None, None, None) + tuple(rets)
 
 
 class FFNSublayerFn(torch.autograd.Function):
@@ -387,6 +472,7 @@ class FFNSublayerFn(torch.autograd.Function):
         y = torch.empty_like(x2)
         gemm([d_fwd(hmid, W2, y, bias=b2, residual=x2)])
         ctx.save_for_backward(x2, z, mean, rstd, hmid, ln_w, W1, W2)
+        ctx.params = live(ln_w, ln_b, W1, b1, W2, b2)
         ctx.shape = shape
         return y.view(shape)
 
@@ -395,13 +481,15 @@ class FFNSublayerFn(torch.autograd.Function):
         x2, z, mean, rstd, hmid, ln_w, W1, W2 = ctx.saved_tensors
         d = x2.shape[1]
         dy2 = _c(dy).view(-1, d)
-        dlnw, dlnb, dW1, db1, dW2, db2 = zeros_like_many([ln_w, ln_w, W1, W1.new_empty(W1.shape[0]), W2, ln_w])
+        (_, _, dW1, db1, dW2, db2), rets = grad_buffers(list(ctx.params))
+        (dlnw, dlnb), _ = ln_param_buffers(ctx.params[0], ctx.params[1], ln_w)
         dh = torch.empty_like(hmid)
-        gemm([d_dgrad([dy2], [W2], dh, relu_src=hmid), d_wgrad(dy2, hmid, dW2, db2)])
+        gemm([d_dgrad([dy2], [W2], dh, relu_src=hmid)] + wgrad_descs(dy2, hmid, dW2, db2))
         dz = torch.empty_like(z)
-        gemm([d_dgrad([dh], [W1], dz), d_wgrad(dh, z, dW1, db1)])
+        gemm([d_dgrad([dh], [W1], dz)] + wgrad_descs(dh, z, dW1, db1))
         dx = ln_bwd(dz, x2, ln_w, mean, rstd, dlnw, dlnb, dx_add=dy2)
-        return dx.view(ctx.shape), dlnw, dlnb, dW1, db1, dW2, db2
+        grads_written(ctx.params)
+        return (dx.view(ctx.shape),) + tuple(rets)
 
 
 def attn_sublayer(x, kv_src, mask, h, ln, mha):
@@ -430,6 +518,7 @@ class GeneratorFn(torch.autograd.Function):
         r = Rows(V, 0, 0)
         call("nast_log_softmax_fwd_f32", _p(y), r, _p(y), r, y.shape[0], V, 1.0 / temperature, _stream())
         ctx.save_for_backward(x2, W, y)
+        ctx.params = live(W, b)
         ctx.it, ctx.xshape = 1.0 / temperature, x.shape
         return y.view(*x.shape[:-1], V)
 
@@ -441,10 +530,11 @@ class GeneratorFn(torch.autograd.Function):
         gl = torch.empty_like(y)
         r = Rows(V, 0, 0)
         call("nast_log_softmax_bwd_f32", _p(gy2), r, _p(y), r, _p(gl), r, y.shape[0], V, ctx.it, _stream())
-        dW, db = zeros_like_many([W, W.new_empty(V)])
+        (dW, db), (rW, rb) = grad_buffers(list(ctx.params))
         dx = torch.empty_like(x2)
-        gemm([d_dgrad([gl], [W], dx), d_wgrad(gl, x2, dW, db)])
-        return dx.view(ctx.xshape), dW, db, None
+        gemm([d_dgrad([gl], [W], dx)] + wgrad_descs(gl, x2, dW, db))
+        grads_written(ctx.params)
+        return dx.view(ctx.xshape), rW, rb, None
 
 
 def generator(x, W, b, temperature):
@@ -551,35 +641,30 @@ class EmbedFn(torch.autograd.Function):
         call("nast_embed_fwd_f32", _p(out), B, L, d, ne, _p(tokens) if hard else None, _p(tok_w) if hard else None,
              None if hard else _p(tokens), _p(pos_w), _p(ew0), _p(ei0), _p(ew1), _p(ei1), _stream())
         ctx.save_for_backward(tokens if hard else None, ei0, ei1)
-        ctx.meta = (hard, B, L, d, ne, tok_w.shape if tok_w is not None else None, pos_w.shape,
-                    ew0.shape if ew0 is not None else None, ew1.shape if ew1 is not None else None)
+        ctx.meta = (hard, B, L, d, ne)
+        ctx.params = live(tok_w if hard else None, pos_w, ew0, ew1)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         ids, ei0, ei1 = ctx.saved_tensors
-        hard, B, L, d, ne, tws, pws, e0s, e1s = ctx.meta
+        hard, B, L, d, ne = ctx.meta
         dout = _c(dout)
-        dev = dout.device
-        d_tokw = torch.zeros(tws, device=dev, dtype=F32) if (hard and ctx.needs_input_grad[1]) else None
-        d_rows = torch.empty(B, L, d, device=dev, dtype=F32) if not hard else None
-        d_pos = torch.zeros(pws, device=dev, dtype=F32)
-        d_e0 = torch.zeros(e0s, device=dev, dtype=F32) if e0s is not None else None
-        d_e1 = torch.zeros(e1s, device=dev, dtype=F32) if e1s is not None else None
+        (d_tokw, d_pos, d_e0, d_e1), (r_tokw, r_pos, r_e0, r_e1) = grad_buffers(list(ctx.params))
+        d_rows = torch.empty(B, L, d, device=dout.device, dtype=F32) if not hard else None
         call("nast_embed_bwd_f32", _p(dout), B, L, d, ne, _p(ids), _p(d_tokw), _p(d_rows), _p(d_pos), _p(d_e0), _p(ei0),
              _p(d_e1), _p(ei1), _stream())
-        return (d_rows if not hard else None), d_tokw, d_pos, d_e0, None, d_e1, None
+        grads_written(ctx.params)
+        return (d_rows if not hard else None), r_tokw, r_pos, r_e0, None, r_e1, None
 
 
 def embed_assemble(tokens, tok_w, pos_w, extra=()):
     """extra: up to two (weight [n,d], index [B] int64 or None) pairs placed in front of the tokens."""
     ew0 = ei0 = ew1 = ei1 = None
     if len(extra) > 0:
-        ew0, ei0 = extra[0]
-        ew0 = ew0.view(-1, ew0.shape[-1])
+        ew0, ei0 = extra[0]       # the parameter itself ([n,d] table or a single [d] row): gradients go to its .grad
     if len(extra) > 1:
         ew1, ei1 = extra[1]
-        ew1 = ew1.view(-1, ew1.shape[-1])
     return EmbedFn.apply(tokens, tok_w, pos_w, ew0, ei0, ew1, ei1)
 
 
@@ -639,6 +724,29 @@ class AlignLSEFn(torch.autograd.Function):
 
 def align_lse(cost0, cost, origin_length, target_length, tau=1.0):
     return AlignLSEFn.apply(cost0, cost, origin_length, target_length, float(tau))
+
+
+class TableRowFn(torch.autograd.Function):
+    """weight[idx] as a [d] tensor (embed.token_embed.weight[eos_id], transformer.py:468-469); the gradient is added
+    to row idx of weight.grad in place instead of going through a zero-filled [V, d] temporary."""
+
+    @staticmethod
+    def forward(ctx, weight, idx):
+        ctx.params = live(weight)
+        ctx.idx = int(idx)
+        return weight.detach()[ctx.idx].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dW,), (rW,) = grad_buffers(list(ctx.params))
+        if dW is not None:
+            dW[ctx.idx] += g
+        grads_written(ctx.params)
+        return rW, None
+
+
+def table_row(weight, idx):
+    return TableRowFn.apply(weight, idx)
 
 
 class LPGatherFn(torch.autograd.Function):

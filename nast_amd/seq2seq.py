@@ -164,7 +164,7 @@ class Seq2seq(BaseModel):
         batch_size = inp_tokens.size(0)
         token_mask = (inp_tokens != pad_idx).float()
 
-        self.optimizer_F.zero_grad()
+        self.optimizer_F.zero_grad(set_to_none=False)   # gradient buffers persist: the HIP kernels accumulate in place
 
         noise_inp_tokens, noise_inp_lengths = self.net.noiseLayer(inp_tokens.transpose(0, 1), inp_lengths, rev_domain=rev_styles)
         noise_inp_tokens = noise_inp_tokens.transpose(0, 1).contiguous()
@@ -179,7 +179,7 @@ class Seq2seq(BaseModel):
 
         last_backward = not cyc_rec_enable
         if last_backward:
-            self.reducer_F.arm()
+            self.reducer_F.arm("f_pretrain")
         if args.use_learnable:
             slf_rec_length_loss = self._length_loss(slf_length_losses, inp_lengths, batch_size)
             (slf_rec_loss + slf_rec_length_loss).backward()
@@ -208,7 +208,17 @@ class Seq2seq(BaseModel):
         cyc_rec_loss = cyc_rec_loss * args.cyc_factor
         cyc_rec_length_loss = self._length_loss(cyc_length_losses, inp_lengths, batch_size) if args.use_learnable else None
 
-        adv_log_probs = self.net.model_D(gen_soft_tokens, gen_lengths, rev_styles)
+        # the discriminator's own parameter gradients are never used by f_step (the reference computes and
+        # discards them: optimizer_D.zero_grad() precedes the next use, seq2seq.py:635), so its weights are
+        # frozen for this forward and the weight-gradient GEMMs are not issued
+        d_params = [p for p in self.net.model_D.parameters() if p.requires_grad]
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            adv_log_probs = self.net.model_D(gen_soft_tokens, gen_lengths, rev_styles)
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
         if args.discriminator_method == 'Multi':
             adv_labels = rev_styles + 1
         else:
@@ -217,7 +227,7 @@ class Seq2seq(BaseModel):
         adv_factor = (raw_styles == 0) * args.fw_adv_factor + (raw_styles == 1) * args.bw_adv_factor
         adv_loss = (adv_loss * adv_factor).sum() / batch_size
 
-        self.reducer_F.arm()
+        self.reducer_F.arm("f_full")
         if args.use_learnable:
             (cyc_rec_loss + adv_loss + cyc_rec_length_loss).backward()
         else:
@@ -280,8 +290,8 @@ class Seq2seq(BaseModel):
         assert len(adv_loss.size()) == 1
         adv_loss = adv_loss.sum() / batch_size
 
-        self.optimizer_D.zero_grad()
-        self.reducer_D.arm()
+        self.optimizer_D.zero_grad(set_to_none=False)
+        self.reducer_D.arm("d")
         adv_loss.backward()
         self.reducer_D.finish()
         self.last_grad_norm = clip_grad_norm_(model_D.parameters(), 5)

@@ -516,8 +516,8 @@ class LengthPredictor(nn.Module):
         S1 = origin_input.shape[1]
         d = self.args.d_model
         dev = origin_input.device
-        eos_embed = embed.token_embed.weight[dm.eos_id]
-        unk_embed = embed.token_embed.weight[dm.unk_id]
+        eos_embed = ops.table_row(embed.token_embed.weight, dm.eos_id)      # :468-469 (live parameters)
+        unk_embed = ops.table_row(embed.token_embed.weight, dm.unk_id)
         src_mask = _pad_mask(origin_length, S1 - 1, 1)
         memory = origin_input
 

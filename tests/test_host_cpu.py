@@ -158,32 +158,73 @@ DDP_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from nast_amd.ddp import GradReducer
+from nast_amd import ops
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 torch.manual_seed(0)
-net = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 4))
-unused = torch.nn.Parameter(torch.zeros(3))                      # like sos_token: never gets a gradient
-params = list(net.parameters()) + [unused]
-red = GradReducer(params, bucket_bytes=4096)
-ref = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 4))
+mk = lambda: torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 4))
+net, ref = mk(), mk()
 ref.load_state_dict(net.state_dict())
+unused = torch.nn.Parameter(torch.zeros(3))                      # like sos_token: never gets a gradient
+w2 = torch.nn.Parameter(torch.rand(4) + 0.5)                     # gradient written IN PLACE, twice per backward
+w2_ref = torch.nn.Parameter(w2.detach().clone())
+params = list(net.parameters()) + [unused, w2]
+red = GradReducer(params, bucket_bytes=4096)
+
+
+class InPlaceScale(torch.autograd.Function):                    # the pattern of the HIP backward kernels
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.w = w
+        ctx.save_for_backward(x)
+        return x * w.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        w = ctx.w
+        if w.grad is None:
+            w.grad = torch.zeros_like(w)
+        w.grad += (g * x).sum(0)
+        ops.grad_listener(w)
+        return g * w.detach(), None
+
+
+def fwd(m, X, w, inplace):
+    y = m(X)
+    if inplace:
+        return InPlaceScale.apply(InPlaceScale.apply(y, w).tanh(), w)
+    return (y * w).tanh() * w
+
+
 g = torch.Generator().manual_seed(5)
-for step in range(3):
+for step in range(4):
     X = torch.randn(2 * world * 4, 16, generator=g); Y = torch.randn(2 * world * 4, 4, generator=g)
     Xa, Ya = X[: world * 4], Y[: world * 4]; Xb, Yb = X[world * 4:], Y[world * 4:]
     sl = slice(rank * 4, rank * 4 + 4)
     for p in params: p.grad = None
     # two backward passes accumulating into the same grads; only the second is reduced (f_step pattern)
-    ((net(Xa[sl]) - Ya[sl]) ** 2).sum().div(4).backward()
-    red.arm()
-    ((net(Xb[sl]) - Yb[sl]) ** 2).sum().div(4).backward()
+    ((fwd(net, Xa[sl], w2, True) - Ya[sl]) ** 2).sum().div(4).backward()
+    red.arm("two-pass")
+    ((fwd(net, Xb[sl], w2, True) - Yb[sl]) ** 2).sum().div(4).backward()
     red.finish()
-    for p in ref.parameters(): p.grad = None
-    (((ref(Xa) - Ya) ** 2).sum() / (4 * world) + ((ref(Xb) - Yb) ** 2).sum() / (4 * world)).backward()
-    for p, q in zip(net.parameters(), ref.parameters()):
+    for p in list(ref.parameters()) + [w2_ref]: p.grad = None
+    (((fwd(ref, Xa, w2_ref, False) - Ya) ** 2).sum() / (4 * world) + ((fwd(ref, Xb, w2_ref, False) - Yb) ** 2).sum() / (4 * world)).backward()
+    for p, q in zip(list(net.parameters()) + [w2], list(ref.parameters()) + [w2_ref]):
         assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), (step, (p.grad - q.grad).abs().max())
     assert unused.grad is None
-    assert len(red.plan) > 1
+    assert len(red.plan.buckets) > 1 and red.plan.counts[red.index[id(w2)]] >= 2
+# a step whose graph has MORE in-place contributions than the learnt plan must still be exact (fallback path)
+for p in params: p.grad = None
+X = torch.randn(world * 4, 16, generator=g); Y = torch.randn(world * 4, 4, generator=g)
+sl = slice(rank * 4, rank * 4 + 4)
+red.arm("two-pass")
+((InPlaceScale.apply(fwd(net, X[sl], w2, True), w2) - Y[sl]) ** 2).sum().div(4).backward()
+red.finish()
+for p in list(ref.parameters()) + [w2_ref]: p.grad = None
+(((fwd(ref, X, w2_ref, False) * w2_ref - Y) ** 2).sum() / (4 * world)).backward()
+for p, q in zip(list(net.parameters()) + [w2], list(ref.parameters()) + [w2_ref]):
+    assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), ("changed graph", (p.grad - q.grad).abs().max())
 dist.destroy_process_group()
 print("ok", rank)
 '''

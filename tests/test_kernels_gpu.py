@@ -243,3 +243,45 @@ def test_embed_assemble(ops, soft):
         relclose(rg.grad, rr.grad)
     else:
         relclose(tg.grad, tr.grad)
+
+
+def _lp_gather_ref(oin, olen, allpos, eos, unk, pos, shift, use_stay):
+    """plain-torch restatement of transformer.py:471-473, :488-491 (candidate table + aligned gather)"""
+    B, S1, d = oin.shape
+    T1 = allpos.shape[1]
+    rows = []
+    for b in range(B):
+        for t in range(T1):
+            a = int(allpos[b, t])
+            prev = int(allpos[b, t - 1]) if t > 0 else -1
+            if use_stay and a == prev:
+                r = unk
+            else:
+                p = a + shift
+                r = oin[b, p] if (p == 0 or (0 < p < S1 and p - 1 < int(olen[b]))) else eos
+            rows.append(r + (pos[t] if pos is not None else 0))
+    return torch.stack(rows).view(B, T1, d)
+
+
+@pytest.mark.parametrize("B,S1,T1,d,shift,use_stay,with_pos", [(5, 7, 6, 32, 0, True, True), (70, 12, 14, 64, 0, True, False),
+                                                               (37, 9, 9, 48, 2, False, True)])
+def test_lp_gather_fwd_bwd(ops, B, S1, T1, d, shift, use_stay, with_pos):
+    g = torch.Generator().manual_seed(B + T1)
+    oin = torch.randn(B, S1, d, generator=g)
+    olen = torch.randint(1, S1, (B,), generator=g)
+    steps = torch.randint(0, 3, (B, T1), generator=g)
+    allpos = torch.cumsum(steps, 1).clamp(max=S1 + 1)
+    allpos[:, 0] = 0
+    eos, unk = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    pos = torch.randn(T1 + 2, d, generator=g) if with_pos else None
+    R = torch.randn(B, T1, d, generator=g)
+    ref_in = [t.clone().requires_grad_(True) if t is not None else None for t in (oin, eos, unk, pos)]
+    yref = _lp_gather_ref(ref_in[0], olen, allpos, ref_in[1], ref_in[2], ref_in[3], shift, use_stay)
+    (yref * R).sum().backward()
+    gi = [dev(t).requires_grad_(True) if t is not None else None for t in (oin, eos, unk, pos)]
+    y = ops.lp_gather(gi[0], dev(olen), dev(allpos), gi[1], gi[2], gi[3], shift, use_stay, pos_skip0=False)
+    (y * dev(R)).sum().backward()
+    relclose(y, yref)
+    for a, b in zip(gi, ref_in):
+        if a is not None:
+            relclose(a.grad, b.grad if b.grad is not None else torch.zeros_like(b))
