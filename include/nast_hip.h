@@ -212,6 +212,16 @@ int nast_lp_step_f32(const float* qh, const float* hid, const float* KC, const f
                      float* x_next, const float* norm_w, const float* norm_b,
                      int B, int S1, int d, int step, int ldp, int write_next, void* stream);
 
+/* Skip logits of the teacher-forced branch (transformer.py:504-507, the einsum "bld,bltd->blt" over
+ * wk(candidates_output) gathered by allpos):  out[b,t,0] = qh[b,t].kunk / sqrt(d),
+ * out[b,t,j] = qh[b,t].KC[b, allpos[b,t]+j] / sqrt(d), j = 1..3.   qh [B,T1,d], KC = wk(candidates_input) [B,NC,d]
+ * (NC >= max(allpos)+4), kunk = wk(unk) [d], out / g [B,T1,4].  Backward writes dqh and ACCUMULATES (atomics) into
+ * dKC [B,NC,d] and dkunk [d] (caller zero-initialises).                                                        */
+int nast_lp_logits_fwd_f32(const float* qh, const float* KC, const float* kunk, const int64_t* allpos, float* out,
+                           int B, int T1, int NC, int d, void* stream);
+int nast_lp_logits_bwd_f32(const float* g, const float* qh, const float* KC, const float* kunk, const int64_t* allpos,
+                           float* dqh, float* dKC, float* dkunk, int B, int T1, int NC, int d, void* stream);
+
 /* Whole greedy skip-decoding loop of LengthPredictor.forward (generate branch, transformer.py:525-570) run from
  * native code: candidate table, wk(candidates), cross-attention K/V of all layers, then per step and layer
  * [LN+QKV GEMM] -> attention over the K/V cache -> [out GEMM + residual] -> [LN+q GEMM] -> cross attention ->

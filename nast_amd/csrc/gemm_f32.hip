@@ -13,6 +13,8 @@
 // Layout cases (run-time, per problem; uniform per workgroup):
 //   A: transA=0 -> k-contiguous [M][K]   | transA=1 -> m-contiguous [K][M]   (wgrad: dY^T)
 //   B: transB=1 -> k-contiguous [N][K]   | transB=0 -> n-contiguous [K][N]   (dgrad: W, wgrad: X)
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -629,8 +631,16 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
   plan_and_launch<128, 128, NAST_BK128>(descs, count, stream, true, &tilesL);
   nast_prof_before(1, stream);
   if (skinny) launch_skinny(descs, count, stream);
-  else if (tilesL >= 384) plan_and_launch<128, 128, NAST_BK128>(descs, count, stream, false, nullptr);
-  else plan_and_launch<64, 64, 32>(descs, count, stream, false, nullptr);
+  else {
+    static const int force = [] { const char* e = getenv("NAST_GEMM_TILE"); return e ? atoi(e) : -1; }();   // tuning aid
+    // measured (tools/gemm_bench, NAST_GEMM_TILE=0/2): the 64x64 tile at 4 workgroups per CU beats 128x128 at 2 on
+    // every d_model-sized problem of the step (finer quantisation over 256 CUs, prologue/epilogue of one
+    // workgroup hidden behind three others); 128x128 only wins (3-8 %) once there are thousands of tiles
+    int cfg = tilesL >= 4096 ? 2 : 0;
+    if (force >= 0) cfg = force;
+    if (cfg == 2) plan_and_launch<128, 128, NAST_BK128>(descs, count, stream, false, nullptr);
+    else plan_and_launch<64, 64, 32>(descs, count, stream, false, nullptr);
+  }
   nast_prof_after(1, stream, flops);
   NAST_CHECK_LAUNCH("nast_gemm_f32");
   return NAST_OK;

@@ -158,14 +158,17 @@ __global__ __launch_bounds__(256) void nast_ln_fwd_vec_kernel(const float* __res
   }
 }
 
+// 16 wavefronts per workgroup and at most one workgroup per CU: enough rows in flight to stream at HBM rate while
+// each column of dgamma / dbeta receives <= 256 atomic adds (same-address fp32 atomics serialise at ~20 G/s)
+#define LN_BWD_WAVES 16
 template <int NV>
-__global__ __launch_bounds__(256) void nast_ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(1024) void nast_ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* __restrict__ dx,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               const float* __restrict__ dx_add, int rows_out, int d, int grp,
                                                               int grp_stride, int grp_off) {
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][4][d]
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [2][LN_BWD_WAVES][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 gam[NV], ag[NV], ab[NV];
 #pragma unroll
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void nast_ln_bwd_vec_kernel(const float* __res
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int r = blockIdx.x * 4 + wave; r < rows_out; r += gridDim.x * 4) {
+  for (int r = blockIdx.x * LN_BWD_WAVES + wave; r < rows_out; r += gridDim.x * LN_BWD_WAVES) {
     const int64_t ir = ln_in_row(r, grp, grp_stride, grp_off);
     const float* xr = x + ir * d;
     const float* gr = dy + (int64_t)r * d;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void nast_ln_bwd_vec_kernel(const float* __res
     }
   }
   float* rg = red;
-  float* rb = red + 4 * d;
+  float* rb = red + LN_BWD_WAVES * d;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = 4 * lane + 256 * i;
@@ -221,9 +224,15 @@ __global__ __launch_bounds__(256) void nast_ln_bwd_vec_kernel(const float* __res
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < d; c += 256) {
-    atomicAdd(dgamma + c, rg[c] + rg[d + c] + rg[2 * d + c] + rg[3 * d + c]);
-    atomicAdd(dbeta + c, rb[c] + rb[d + c] + rb[2 * d + c] + rb[3 * d + c]);
+  for (int c = threadIdx.x; c < d; c += LN_BWD_WAVES * 64) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < LN_BWD_WAVES; ++w) {
+      sg += rg[w * d + c];
+      sb += rb[w * d + c];
+    }
+    atomicAdd(dgamma + c, sg);
+    atomicAdd(dbeta + c, sb);
   }
 }
 
@@ -271,19 +280,30 @@ extern "C" int nast_layernorm_bwd_f32(const float* dy, const float* x, const flo
     }
   }
   if (rows_out == 0) return NAST_OK;
-  int blocks = (rows_out + 3) / 4;
-  if (blocks > 2048) blocks = 2048;     // 8 workgroups per CU keep enough rows in flight; <= 2048 atomics per column
-  const size_t lds = 2 * 4 * d * sizeof(float);
   const bool vec = ln_vec_ok(d, {dy, x, gamma, dx, dx_add});
-  if (vec && d <= 256)
-    hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<1>, dim3(blocks), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
-  else if (vec && d <= 512)
-    hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<2>, dim3(blocks), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
-  else if (vec)
-    hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<4>, dim3(blocks), dim3(256), lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
-  else
-    hipLaunchKernelGGL(nast_ln_bwd_kernel, dim3(blocks < 512 ? blocks : 512), dim3(256), lds, s, dy, x, gamma, mean, rstd,
+  if (vec) {
+    int blocks = (rows_out + LN_BWD_WAVES - 1) / LN_BWD_WAVES;
+    if (blocks > 256) blocks = 256;
+    const size_t lds = (size_t)2 * LN_BWD_WAVES * d * sizeof(float);
+    const dim3 grid(blocks), block(LN_BWD_WAVES * 64);
+    if (d <= 256) {
+      hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<1>, grid, block, lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+    } else if (d <= 512) {
+      hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<2>, grid, block, lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+    } else {
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute((const void*)nast_ln_bwd_vec_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LN_BWD_WAVES * 1024 * 4);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<4>, grid, block, lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+    }
+  } else {
+    int blocks = (rows_out + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(nast_ln_bwd_kernel, dim3(blocks), dim3(256), 2 * 4 * d * sizeof(float), s, dy, x, gamma, mean, rstd,
                        dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+  }
   NAST_CHECK_LAUNCH("nast_layernorm_bwd_f32");
   return NAST_OK;
 }

@@ -82,3 +82,84 @@ extern "C" int nast_lp_step_f32(const float* qh, const float* hid, const float* 
   NAST_CHECK_LAUNCH("nast_lp_step_f32");
   return NAST_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Skip logits of the teacher-forced branch (transformer.py:504-507):
+//   out[b,t,0] = qh[b,t] . kunk / sqrt(d),   out[b,t,j] = qh[b,t] . KC[b, allpos[b,t] + j] / sqrt(d)   (j = 1..3)
+// (wk is linear, so wk(candidates_output)[b,t,j] is a row of KC = wk(candidates_input) -- the [B,S+2,4,d] table of
+// the reference is never built).  One wavefront per (sentence, position).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nast_lp_logits_fwd_kernel(const float* __restrict__ qh, const float* __restrict__ KC,
+                                                                 const float* __restrict__ kunk, const int64_t* __restrict__ allpos,
+                                                                 float* __restrict__ out, int B, int T1, int NC, int d, float inv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * T1) return;
+  const int b = row / T1;
+  const int64_t a = allpos[row];
+  const float* q = qh + row * d;
+  float dot[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = lane; c < d; c += 64) {
+    const float qv = q[c];
+    dot[0] = fmaf(qv, kunk[c], dot[0]);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) dot[j] = fmaf(qv, KC[((int64_t)b * NC + a + j) * d + c], dot[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dot[j] = wave_sum(dot[j]) * inv;
+  if (lane == 0) *reinterpret_cast<float4*>(out + row * 4) = make_float4(dot[0], dot[1], dot[2], dot[3]);
+}
+
+// workgroup = (position t, chunk of 32 sentences): dqh written, dKC scattered with atomics (distinct rows), the shared
+// dkunk summed per wavefront first (one atomic per column per wavefront)
+#define LPL_BPB 32
+__global__ __launch_bounds__(256) void nast_lp_logits_bwd_kernel(const float* __restrict__ g, const float* __restrict__ qh,
+                                                                 const float* __restrict__ KC, const float* __restrict__ kunk,
+                                                                 const int64_t* __restrict__ allpos, float* __restrict__ dqh,
+                                                                 float* __restrict__ dKC, float* __restrict__ dkunk, int B, int T1,
+                                                                 int NC, int d, float inv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x;
+  const int b0 = blockIdx.y * LPL_BPB;
+  for (int c = lane; c < d; c += 64) {
+    float s_unk = 0.f;
+    const float ku = kunk[c];
+    for (int b = b0 + wave; b < B && b < b0 + LPL_BPB; b += 4) {
+      const int64_t row = (int64_t)b * T1 + t;
+      const float4 gv = *reinterpret_cast<const float4*>(g + row * 4);
+      const int64_t a = allpos[row];
+      const float qv = qh[row * d + c];
+      const float* k1 = KC + ((int64_t)b * NC + a + 1) * d + c;
+      dqh[row * d + c] = inv * (gv.x * ku + gv.y * k1[0] + gv.z * k1[d] + gv.w * k1[2 * d]);
+      s_unk = fmaf(gv.x, qv, s_unk);
+      float* dk1 = dKC + ((int64_t)b * NC + a + 1) * d + c;
+      atomicAdd(dk1, inv * gv.y * qv);
+      atomicAdd(dk1 + d, inv * gv.z * qv);
+      atomicAdd(dk1 + 2 * d, inv * gv.w * qv);
+    }
+    atomicAdd(dkunk + c, inv * s_unk);
+  }
+}
+
+extern "C" int nast_lp_logits_fwd_f32(const float* qh, const float* KC, const float* kunk, const int64_t* allpos, float* out,
+                                      int B, int T1, int NC, int d, void* stream) {
+  NAST_REQUIRE(B >= 0 && T1 >= 1 && NC >= 4 && d >= 1, "nast_lp_logits_fwd_f32: bad sizes");
+  if (B == 0) return NAST_OK;
+  NAST_REQUIRE(qh && KC && kunk && allpos && out, "nast_lp_logits_fwd_f32: NULL pointer");
+  const int64_t rows = (int64_t)B * T1;
+  hipLaunchKernelGGL(nast_lp_logits_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, qh, KC, kunk, allpos, out,
+                     B, T1, NC, d, 1.0f / sqrtf((float)d));
+  NAST_CHECK_LAUNCH("nast_lp_logits_fwd_f32");
+  return NAST_OK;
+}
+
+extern "C" int nast_lp_logits_bwd_f32(const float* g, const float* qh, const float* KC, const float* kunk, const int64_t* allpos,
+                                      float* dqh, float* dKC, float* dkunk, int B, int T1, int NC, int d, void* stream) {
+  NAST_REQUIRE(B >= 0 && T1 >= 1 && NC >= 4 && d >= 1, "nast_lp_logits_bwd_f32: bad sizes");
+  if (B == 0) return NAST_OK;
+  NAST_REQUIRE(g && qh && KC && kunk && allpos && dqh && dKC && dkunk, "nast_lp_logits_bwd_f32: NULL pointer");
+  hipLaunchKernelGGL(nast_lp_logits_bwd_kernel, dim3(T1, (B + LPL_BPB - 1) / LPL_BPB), dim3(256), 0, (hipStream_t)stream, g, qh, KC,
+                     kunk, allpos, dqh, dKC, dkunk, B, T1, NC, d, 1.0f / sqrtf((float)d));
+  NAST_CHECK_LAUNCH("nast_lp_logits_bwd_f32");
+  return NAST_OK;
+}

@@ -783,3 +783,35 @@ class LPGatherFn(torch.autograd.Function):
 
 def lp_gather(origin_input, origin_length, allpos, eos, unk, pos_w=None, shift=0, use_stay=True, pos_skip0=True):
     return LPGatherFn.apply(origin_input, origin_length, allpos, eos, unk, pos_w, int(shift), int(use_stay), int(pos_skip0))
+
+
+class LPLogitsFn(torch.autograd.Function):
+    """Bilinear part of the skip logits (transformer.py:504-507) without the [B,T1,3,d] gather / einsum tensors."""
+
+    @staticmethod
+    def forward(ctx, qh, KC, kunk, allpos):
+        _chk(qh, KC, kunk)
+        qh, KC, kunk, allpos = _c(qh), _c(KC), _c(kunk), _c(allpos)
+        B, T1, d = qh.shape
+        NC = KC.shape[1]
+        out = torch.empty(B, T1, 4, device=qh.device, dtype=F32)
+        call("nast_lp_logits_fwd_f32", _p(qh), _p(KC), _p(kunk), _p(allpos), _p(out), B, T1, NC, d, _stream())
+        ctx.save_for_backward(qh, KC, kunk, allpos)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qh, KC, kunk, allpos = ctx.saved_tensors
+        B, T1, d = qh.shape
+        NC = KC.shape[1]
+        g = _c(g)
+        dqh = torch.empty_like(qh)
+        dKC = torch.zeros_like(KC)
+        dkunk = torch.zeros_like(kunk)
+        call("nast_lp_logits_bwd_f32", _p(g), _p(qh), _p(KC), _p(kunk), _p(allpos), _p(dqh), _p(dKC), _p(dkunk), B, T1, NC, d,
+             _stream())
+        return dqh, dKC, dkunk, None
+
+
+def lp_logits(qh, KC, kunk, allpos):
+    return LPLogitsFn.apply(qh, KC, kunk, allpos)

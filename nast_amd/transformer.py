@@ -540,11 +540,7 @@ class LengthPredictor(nn.Module):
             KC = self.wk(cand_in)                                             # [B,S1+5,d]
             kunk = self.wk(unk_embed.view(1, d))                              # [1,d]
             qh = self.wq(hidden)                                              # [B,T1,d]
-            idx = allpos.unsqueeze(-1) + torch.arange(1, self.max_skip, device=dev)                  # [B,T1,3]
-            selK = torch.gather(KC, 1, idx.view(batch_size, -1, 1).expand(-1, -1, d)).view(batch_size, T1, self.max_skip - 1, d)
-            l0 = torch.matmul(qh, kunk.t())                                                          # [B,T1,1]
-            lr = torch.einsum("bld,bljd->blj", qh, selK)
-            logits = torch.cat((l0, lr), -1) / self.sqrt_d_model
+            logits = ops.lp_logits(qh, KC, kunk.view(d), allpos)                                      # [B,T1,4], already / sqrt(d)
             logits = logits + self.linear(hidden)
             target = torch.cat([allpos[:, 1:], origin_length.unsqueeze(-1) + 1], dim=1) - allpos     # :509
             gen_err = (target >= 4).sum().float() / target.shape[0]                                  # :511

@@ -285,3 +285,22 @@ def test_lp_gather_fwd_bwd(ops, B, S1, T1, d, shift, use_stay, with_pos):
     for a, b in zip(gi, ref_in):
         if a is not None:
             relclose(a.grad, b.grad if b.grad is not None else torch.zeros_like(b))
+
+
+@pytest.mark.parametrize("B,T1,S1,d", [(3, 5, 6, 32), (70, 9, 11, 64), (33, 17, 17, 256)])
+def test_lp_skip_logits(ops, B, T1, S1, d):
+    """transformer.py:504-507: einsum("bld,bltd->blt", wq(hidden), wk(candidates_output)[allpos]) / sqrt(d)"""
+    g = torch.Generator().manual_seed(B * 7 + d)
+    NC = S1 + 5
+    qh, KC, kunk = torch.randn(B, T1, d, generator=g), torch.randn(B, NC, d, generator=g), torch.randn(d, generator=g)
+    allpos = torch.cumsum(torch.randint(0, 3, (B, T1), generator=g), 1).clamp(max=S1)
+    R = torch.randn(B, T1, 4, generator=g)
+    rq, rK, rk = (t.clone().requires_grad_(True) for t in (qh, KC, kunk))
+    idx = allpos.unsqueeze(-1) + torch.arange(1, 4)
+    sel = torch.gather(rK, 1, idx.view(B, -1, 1).expand(-1, -1, d)).view(B, T1, 3, d)
+    ref = torch.cat((torch.matmul(rq, rk.view(d, 1)), torch.einsum("bld,bljd->blj", rq, sel)), -1) / math.sqrt(d)
+    (ref * R).sum().backward()
+    gq, gK, gk = (dev(t).requires_grad_(True) for t in (qh, KC, kunk))
+    out = ops.lp_logits(gq, gK, gk, dev(allpos))
+    (out * dev(R)).sum().backward()
+    relclose(out, ref); relclose(gq.grad, rq.grad); relclose(gK.grad, rK.grad); relclose(gk.grad, rk.grad)
