@@ -122,6 +122,13 @@ int nast_log_softmax_fwd_f32(const float* x, nast_rows xr, float* y, nast_rows y
 /* gx = (gy - exp(y) * sum(gy)) * inv_temp */
 int nast_log_softmax_bwd_f32(const float* gy, nast_rows gyr, const float* y, nast_rows yr,
                              float* gx, nast_rows gxr, int rows, int V, float inv_temp, void* stream);
+/* NLL of the gold token on log-probabilities and its backward fused with the log-softmax backward
+ * (nn.NLLLoss(reduction='none') at seq2seq.py:453, :504 applied to Generator's output, transformer.py:214):
+ *   nll[r] = -y[r, tokens[r]];   gx[r, v] = g[r] * (exp(y[r, v]) - [v == tokens[r]]) * inv_temp
+ * tokens int64 [rows] must lie in [0, V).  The dense gradient w.r.t. the log-probabilities is never materialised. */
+int nast_nll_gather_f32(const float* y, nast_rows yr, const int64_t* tokens, float* nll, int rows, int V, void* stream);
+int nast_nll_log_softmax_bwd_f32(const float* g, const float* y, nast_rows yr, const int64_t* tokens, float* gx,
+                                 nast_rows gxr, int rows, int V, float inv_temp, void* stream);
 /* Gumbel-softmax sample, utils/gumbel.py:9-69:
  *   g = min(-log(E), 1e10), z = (logits + g) * inv_tau, (mask==0 -> z = -1e9), y = softmax(z), idx = argmax(y)
  * E: the Exp(1) draw (injected noise, parity mode) or NULL -> in-kernel Philox4x32-10 keyed by (seed, offset).

@@ -78,6 +78,36 @@ __global__ __launch_bounds__(256) void nast_log_softmax_bwd_kernel(const float* 
   for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) op[c] = (gp[c] - __expf(yp[c]) * s) * it;
 }
 
+// NLL of the gold token fused with the log-softmax backward (seq2seq.py:453-455, :504-506 + transformer.py:214):
+//   nll[r] = -y[r, tok[r]];   d logits[r, v] = g[r] * (exp(y[r, v]) - [v == tok[r]]) * it
+// so the [rows, V] gradient of the log-probabilities (zero-fill + scatter + transposing copy in eager PyTorch) never exists.
+__global__ __launch_bounds__(256) void nast_nll_gather_kernel(const float* __restrict__ y, nast_rows yr, const int64_t* __restrict__ tok,
+                                                              float* __restrict__ out, int rows) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < rows) out[r] = -y[row_offset(r, yr) + tok[r]];
+}
+
+__global__ __launch_bounds__(256) void nast_nll_log_softmax_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                                       nast_rows yr, const int64_t* __restrict__ tok,
+                                                                       float* __restrict__ gx, nast_rows gxr, int V, float it) {
+  const int64_t r = blockIdx.x;
+  const float* yp = y + row_offset(r, yr);
+  float* op = gx + row_offset(r, gxr);
+  const RowSpan sp = row_span(V, ptr16(yp) && ptr16(op));
+  const float gr = g[r] * it;
+  const int t = (int)tok[r];
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    const float4 l = reinterpret_cast<const float4*>(yp)[c];
+    float4 o;
+    o.x = gr * (__expf(l.x) - (4 * c == t ? 1.f : 0.f));
+    o.y = gr * (__expf(l.y) - (4 * c + 1 == t ? 1.f : 0.f));
+    o.z = gr * (__expf(l.z) - (4 * c + 2 == t ? 1.f : 0.f));
+    o.w = gr * (__expf(l.w) - (4 * c + 3 == t ? 1.f : 0.f));
+    reinterpret_cast<float4*>(op)[c] = o;
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) op[c] = gr * (__expf(yp[c]) - (c == t ? 1.f : 0.f));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Gumbel softmax
 // ---------------------------------------------------------------------------------------------
@@ -318,5 +348,24 @@ extern "C" int nast_first_eos_length_i64(const int64_t* tokens, int64_t* lengths
   NAST_REQUIRE(tokens && lengths, "nast_first_eos_length_i64: NULL pointer");
   hipLaunchKernelGGL(nast_first_eos_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, tokens, lengths, B, L, eos);
   NAST_CHECK_LAUNCH("nast_first_eos_length_i64");
+  return NAST_OK;
+}
+
+extern "C" int nast_nll_gather_f32(const float* y, nast_rows yr, const int64_t* tokens, float* nll, int rows, int V, void* stream) {
+  NAST_REQUIRE(rows >= 0 && V >= 1, "nast_nll_gather_f32: bad sizes");
+  if (rows == 0) return NAST_OK;
+  NAST_REQUIRE(y && tokens && nll, "nast_nll_gather_f32: NULL pointer");
+  hipLaunchKernelGGL(nast_nll_gather_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, y, yr, tokens, nll, rows);
+  NAST_CHECK_LAUNCH("nast_nll_gather_f32");
+  return NAST_OK;
+}
+
+extern "C" int nast_nll_log_softmax_bwd_f32(const float* g, const float* y, nast_rows yr, const int64_t* tokens, float* gx,
+                                            nast_rows gxr, int rows, int V, float inv_temp, void* stream) {
+  NAST_REQUIRE(rows >= 0 && V >= 1, "nast_nll_log_softmax_bwd_f32: bad sizes");
+  if (rows == 0) return NAST_OK;
+  NAST_REQUIRE(g && y && tokens && gx, "nast_nll_log_softmax_bwd_f32: NULL pointer");
+  hipLaunchKernelGGL(nast_nll_log_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, y, yr, tokens, gx, gxr, V, inv_temp);
+  NAST_CHECK_LAUNCH("nast_nll_log_softmax_bwd_f32");
   return NAST_OK;
 }

@@ -537,6 +537,47 @@ class GeneratorFn(torch.autograd.Function):
         return dx.view(ctx.xshape), rW, rb, None
 
 
+class GeneratorNLLFn(torch.autograd.Function):
+    """-log_softmax((x W^T + b) / temperature)[token]  per row: Generator (transformer.py:213-214) + NLLLoss(reduction
+    ='none') (seq2seq.py:453, :504) as one node, so the gradient of the [rows, V] log-probabilities never exists."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, temperature, tokens):
+        _chk(x, W, b)
+        x2 = _c(x).view(-1, x.shape[-1])
+        V = W.shape[0]
+        tokens = _c(tokens).view(-1)
+        assert tokens.numel() == x2.shape[0] and tokens.dtype == torch.int64
+        y = torch.empty(x2.shape[0], V, device=x.device, dtype=F32)
+        gemm([d_fwd(x2, W, y, bias=b)])
+        r = Rows(V, 0, 0)
+        call("nast_log_softmax_fwd_f32", _p(y), r, _p(y), r, y.shape[0], V, 1.0 / temperature, _stream())
+        nll = torch.empty(x2.shape[0], device=x.device, dtype=F32)
+        call("nast_nll_gather_f32", _p(y), r, _p(tokens), _p(nll), y.shape[0], V, _stream())
+        ctx.save_for_backward(x2, W, y, tokens)
+        ctx.params = live(W, b)
+        ctx.it, ctx.xshape = 1.0 / temperature, x.shape
+        return nll.view(x.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, W, y, tokens = ctx.saved_tensors
+        V = W.shape[0]
+        g = _c(g).view(-1)
+        r = Rows(V, 0, 0)
+        gl = torch.empty_like(y)
+        call("nast_nll_log_softmax_bwd_f32", _p(g), _p(y), r, _p(tokens), _p(gl), r, y.shape[0], V, ctx.it, _stream())
+        (dW, db), (rW, rb) = grad_buffers(list(ctx.params))
+        dx = torch.empty_like(x2)
+        gemm([d_dgrad([gl], [W], dx)] + wgrad_descs(gl, x2, dW, db))
+        grads_written(ctx.params)
+        return dx.view(ctx.xshape), rW, rb, None, None
+
+
+def generator_nll(x, W, b, temperature, tokens):
+    return GeneratorNLLFn.apply(x, W, b, float(temperature), tokens)
+
+
 def generator(x, W, b, temperature):
     return GeneratorFn.apply(x, W, b, float(temperature))
 

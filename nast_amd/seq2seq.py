@@ -170,10 +170,12 @@ class Seq2seq(BaseModel):
         noise_inp_tokens = noise_inp_tokens.transpose(0, 1).contiguous()
 
         model_F = self.net.model_F
-        slf_log_probs, _, slf_length_losses, slf_gen_error, _ = model_F(
+        # nll_targets: Generator + NLLLoss(reduction='none') (seq2seq.py:453) run as one node on the device
+        slf_nll, _, slf_length_losses, slf_gen_error, _ = model_F(
             noise_inp_tokens, noise_inp_lengths, inp_tokens, inp_lengths, raw_styles,
-            generate=False, differentiable_decode=False, temperature=temperature, use_inference_z=use_inference_z)
-        slf_rec_loss = loss_fn(slf_log_probs.transpose(1, 2), inp_tokens) * token_mask
+            generate=False, differentiable_decode=False, temperature=temperature, use_inference_z=use_inference_z,
+            nll_targets=inp_tokens)
+        slf_rec_loss = slf_nll * token_mask
         slf_rec_loss = slf_rec_loss.sum() / batch_size
         slf_rec_loss = slf_rec_loss * args.slf_factor
 
@@ -200,10 +202,11 @@ class Seq2seq(BaseModel):
         if not args.use_learnable:
             gen_lengths = self.get_lengths(gen_idx, eos_idx)
 
-        cyc_log_probs, _, cyc_length_losses, cyc_gen_error, _ = model_F(
+        cyc_nll, _, cyc_length_losses, cyc_gen_error, _ = model_F(
             gen_soft_tokens, gen_lengths, inp_tokens, inp_lengths, raw_styles,
-            generate=False, differentiable_decode=False, temperature=temperature, use_inference_z=use_inference_z)
-        cyc_rec_loss = loss_fn(cyc_log_probs.transpose(1, 2), inp_tokens) * token_mask
+            generate=False, differentiable_decode=False, temperature=temperature, use_inference_z=use_inference_z,
+            nll_targets=inp_tokens)
+        cyc_rec_loss = cyc_nll * token_mask                                    # seq2seq.py:504
         cyc_rec_loss = cyc_rec_loss.sum() / batch_size
         cyc_rec_loss = cyc_rec_loss * args.cyc_factor
         cyc_rec_length_loss = self._length_loss(cyc_length_losses, inp_lengths, batch_size) if args.use_learnable else None

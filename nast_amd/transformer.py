@@ -211,6 +211,10 @@ class Generator(nn.Module):
     def forward(self, x, temperature):
         return ops.generator(x, self.proj.weight, self.proj.bias, temperature)   # transformer.py:213-214
 
+    def nll(self, x, temperature, tokens):
+        """-forward(x, temperature).gather(-1, tokens): the NLLLoss(reduction='none') of seq2seq.py:453 fused in."""
+        return ops.generator_nll(x, self.proj.weight, self.proj.bias, temperature, tokens)
+
 
 class Decoder(nn.Module):
     def __init__(self, num_layers, d_model, vocab_size, h, dropout):
@@ -219,9 +223,10 @@ class Decoder(nn.Module):
         self.norm = LayerNorm(d_model)
         self.generator = Generator(d_model, vocab_size)
 
-    def forward(self, x, memory, src_mask, tgt_mask, temperature, skip_first=False):
+    def forward(self, x, memory, src_mask, tgt_mask, temperature, skip_first=False, nll_targets=None):
         """transformer.py:180-188.  skip_first=True returns log-probs for positions 1.. only
-        (what StyleTransformer keeps, transformer.py:103) without computing row 0."""
+        (what StyleTransformer keeps, transformer.py:103) without computing row 0; with nll_targets [B, n-1]
+        the per-token negative log-likelihood of those tokens is returned instead of the log-probs."""
         assert x.size(1) == tgt_mask.size(-1)
         y = x
         for layer in self.layers:
@@ -229,6 +234,9 @@ class Decoder(nn.Module):
         B, n, d = y.shape
         if skip_first:
             z = ops.layer_norm_rows(y, self.norm.weight, self.norm.bias, n - 1, n, 1, B * (n - 1))
+            if nll_targets is not None:
+                assert nll_targets.shape == (B, n - 1)
+                return self.generator.nll(z, temperature, nll_targets).view(B, n - 1)
             return self.generator(z, temperature).view(B, n - 1, -1)
         return self.generator(self.norm(y), temperature)
 
@@ -282,8 +290,10 @@ class StyleTransformer(nn.Module):
             self.length_predictor = LengthPredictor(param)
 
     def forward(self, inp_tokens, inp_lengths, gold_tokens, gold_lengths, style,
-                generate=False, differentiable_decode=False, temperature=1.0, *, use_inference_z):
-        """transformer.py:48-103 -> (log_probs[:,1:], tgt_lengths, length_loss, gen_error, allpos)"""
+                generate=False, differentiable_decode=False, temperature=1.0, *, use_inference_z, nll_targets=None):
+        """transformer.py:48-103 -> (log_probs[:,1:], tgt_lengths, length_loss, gen_error, allpos).
+        Extension: nll_targets [B,T] int64 -> the first result is -log_probs[:,1:].gather(-1, nll_targets) [B,T]
+        (what seq2seq.py:453 / :504 compute from the log-probs), without materialising their gradient."""
         batch_size = inp_tokens.size(0)
         max_enc_len = inp_tokens.size(1)
         if self.check_lengths:
@@ -318,7 +328,8 @@ class StyleTransformer(nn.Module):
             tgt_mask = src_mask
             tgt_lengths = length_loss = gen_error = allpos = None
 
-        log_probs = self.decoder(dec_input_emb, memory, src_mask, tgt_mask, temperature, skip_first=True)
+        log_probs = self.decoder(dec_input_emb, memory, src_mask, tgt_mask, temperature, skip_first=True,
+                                 nll_targets=nll_targets)
         return log_probs, tgt_lengths, length_loss, gen_error, allpos
 
 

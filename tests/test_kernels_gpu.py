@@ -304,3 +304,19 @@ def test_lp_skip_logits(ops, B, T1, S1, d):
     out = ops.lp_logits(gq, gK, gk, dev(allpos))
     (out * dev(R)).sum().backward()
     relclose(out, ref); relclose(gq.grad, rq.grad); relclose(gK.grad, rK.grad); relclose(gk.grad, rk.grad)
+
+
+@pytest.mark.parametrize("rows,d,V,temp", [(6, 32, 40, 1.0), (33, 256, 9600, 0.7), (5, 64, 1001, 1.0)])
+def test_generator_nll_fused(ops, rows, d, V, temp):
+    """Generator (transformer.py:213-214) + NLLLoss(reduction='none') (seq2seq.py:453) as one node."""
+    g = torch.Generator().manual_seed(V + rows)
+    x, W, b = torch.randn(rows, d, generator=g), torch.randn(V, d, generator=g) * 0.1, torch.randn(V, generator=g) * 0.1
+    tok = torch.randint(0, V, (rows,), generator=g)
+    w = torch.rand(rows, generator=g)
+    rx, rW, rb = (t.clone().requires_grad_(True) for t in (x, W, b))
+    ref = torch.nn.functional.nll_loss(torch.log_softmax((rx @ rW.t() + rb) / temp, -1), tok, reduction="none")
+    (ref * w).sum().backward()
+    gx, gW, gb = (dev(t).requires_grad_(True) for t in (x, W, b))
+    out = ops.generator_nll(gx, gW, gb, temp, dev(tok))
+    (out * dev(w)).sum().backward()
+    relclose(out, ref); relclose(gx.grad, rx.grad); relclose(gW.grad, rW.grad); relclose(gb.grad, rb.grad)
