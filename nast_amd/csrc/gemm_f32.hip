@@ -31,6 +31,7 @@ struct GemmLaunch {
   int splitk[NAST_GEMM_MAX_GROUP];
   int kt_per_split[NAST_GEMM_MAX_GROUP];
   int count;
+  int xcd_order;
 };
 
 template <int R, int BK>
@@ -160,6 +161,26 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
   const bool va = ((D.lda & 3) == 0) && (!AKC || (K & 3) == 0);
   const bool vb = ((D.ldb & 3) == 0) && (!BKC || (K & 3) == 0);
 
+  // With one 32x32 tile per wavefront (64x64 workgroup tile) the epilogue operands (residual / ReLU mask) are
+  // fetched NOW, in the ownership of the wide epilogue (row p*8 + lane/8, columns 4*(lane%8)..+3), and sit in
+  // registers through the K loop: the epilogue then has no memory round trip before its stores.
+  constexpr bool PREFETCH_EPI = FAST && (MT * NT == 1);
+  float4 pre_r[4], pre_s[4];
+  const bool epi_wide = FAST && (D.flags & NAST_GEMM_VEC_C) && !(D.flags & NAST_GEMM_ATOMIC);
+  if (PREFETCH_EPI && epi_wide) {
+    const int c4 = (lane & 7) * 4;
+    const int col = n0 + wn * WTN + c4;
+    const bool col_ok = col < N;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int row = m0 + wm * WTM + p * 8 + (lane >> 3);
+      row = row < M ? row : M - 1;
+      const int64_t o = (int64_t)row * D.ldc + (col_ok ? col : 0);
+      pre_r[p] = (D.residual != nullptr && kz == 0) ? *reinterpret_cast<const float4*>(D.residual + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pre_s[p] = D.relu_src != nullptr ? *reinterpret_cast<const float4*>(D.relu_src + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+  }
+
   float4 ra[GA::NV], rb[GB::NV];
   auto issue = [&](int step) {
     const int s = step / nk;
@@ -191,9 +212,11 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
 #pragma unroll
     for (int b = 0; b < NT; ++b) fb[0][b] = frag_read<BN, BK, BKC>(Bs, wn * WTN + b * 32 + li, 0, lh);
     if (!AKC) {
-      if (do_colsum && threadIdx.x < BM) {
+      if (do_colsum) {   // bias gradient: all 256 threads share the column sums of this K-tile (m = tid % BM, a slice of k)
+        constexpr int PARTS = 256 / BM, KP = BK / PARTS;
+        const int cm = threadIdx.x % BM, k0c = (threadIdx.x / BM) * KP;
 #pragma unroll
-        for (int k = 0; k < BK; ++k) colacc += As[k * GA::MC_LD + threadIdx.x];
+        for (int k = 0; k < KP; ++k) colacc += As[(k0c + k) * GA::MC_LD + cm];
       }
     }
 #pragma unroll
@@ -235,8 +258,8 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
 
   // ---- epilogue ----
   if (!AKC) {
-    if (do_colsum && threadIdx.x < BM && (m0 + (int)threadIdx.x) < M && steps > 0)
-      atomicAdd(D.colsum + m0 + threadIdx.x, colacc);
+    if (do_colsum && (m0 + (int)(threadIdx.x % BM)) < M && steps > 0)
+      atomicAdd(D.colsum + m0 + threadIdx.x % BM, colacc);
   }
   const bool first = (kz == 0);
   const float alpha = D.alpha;
@@ -274,8 +297,13 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
           int row = m0 + wm * WTM + a * 32 + rl;
           row = row < M ? row : M - 1;
           const int64_t o = (int64_t)row * ldc + (col_ok ? col : 0);
-          rv[p] = has_res ? *reinterpret_cast<const float4*>(resid + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-          sv[p] = has_rsrc ? *reinterpret_cast<const float4*>(rsrc + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+          if (PREFETCH_EPI) {
+            rv[p] = pre_r[p];
+            sv[p] = pre_s[p];
+          } else {
+            rv[p] = has_res ? *reinterpret_cast<const float4*>(resid + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sv[p] = has_rsrc ? *reinterpret_cast<const float4*>(rsrc + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+          }
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -337,7 +365,15 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
   using GB = TileGeom<BN, BK>;
   __shared__ __attribute__((aligned(16))) float smem[2 * (GA::SZ + GB::SZ)];
   // ---- which problem / tile / k-slice ----
-  const int bid = blockIdx.x;
+  // Optional XCD-contiguous order (NAST_GEMM_XCD=1): workgroups are dealt round-robin over the 8 XCDs, so making the
+  // logical tile index contiguous per XCD lets the N/BN tiles that re-read one A row panel share an L2.  Measured:
+  // +1..8 % on single-problem launches in tools/gemm_bench, but -7 % on the whole step (74.5 -> 80.4 ms): in the
+  // grouped launches (dgrad + wgrads) a contiguous slice per XCD gives the XCDs unequal work.  Default: off.
+  int bid = blockIdx.x;
+  if (P.xcd_order) {
+    const int n = gridDim.x, q = n >> 3, r = n & 7, x = blockIdx.x & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (blockIdx.x >> 3);
+  }
   int gi = 0;
   while (gi + 1 < P.count && bid >= P.tile_start[gi + 1]) ++gi;
   const nast_gemm_desc& D = P.d[gi];
@@ -597,6 +633,8 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
     start += P.tiles_m[i] * P.tiles_n[i] * sk_of[i];
   }
   P = Q;
+  static const int xcd_order = [] { const char* e = getenv("NAST_GEMM_XCD"); return e ? atoi(e) : 0; }();   // tuning aid
+  P.xcd_order = xcd_order;
   for (int i = count; i <= NAST_GEMM_MAX_GROUP; ++i) P.tile_start[i] = start;
   if (start == 0) return 0;
   if (fast_ok<BM, BN, BK>(descs, count))

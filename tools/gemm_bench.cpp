@@ -86,6 +86,15 @@ int main(int argc, char** argv) {
     auto N = [&](const char* s) { snprintf(nm, sizeof(nm), "M=%d %s", M, s); return nm; };
     // forward: y = x W^T
     run(N("fwd  d->d"), {mk(x, W, y, M, d, d, d, d, d, 0, 1)});
+    {
+      nast_gemm_desc o = mk(x, W, y, M, d, d, d, d, d, 0, 1);
+      o.bias = W2; o.residual = y2;
+      run(N("fwd  out-proj d->d + bias + residual"), {o});
+      nast_gemm_desc dg = mk(x, W, y, M, d, d, d, d, d, 0, 0);
+      nast_gemm_desc wg = mk(x, y2, dW, d, d, M, d, d, d, 1, 0, NAST_GEMM_ATOMIC);
+      wg.colsum = dW2;
+      run(N("bwd  out-proj: dgrad + wgrad + bias grad"), {dg, wg});
+    }
     run(N("fwd  QKV grouped x3"), {mk(x, W, y, M, d, d, d, d, d, 0, 1), mk(x, W2, y2, M, d, d, d, d, d, 0, 1), mk(x, W3, y3, M, d, d, d, d, d, 0, 1)});
     run(N("fwd  d->4d"), {mk(x, W, y, M, ff, d, d, d, ff, 0, 1)});
     run(N("fwd  4d->d"), {mk(x, W, y, M, d, ff, ff, ff, d, 0, 1)});
