@@ -129,10 +129,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    torch.cuda.set_device(local_rank)
+    # NAST_DIST_BACKEND=gloo is a rehearsal aid: several ranks may then share one GPU (RCCL needs one GPU per rank)
+    backend = os.environ.get("NAST_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     learnable = a.alignment == "learnable"
     L = a.max_length or (32 if learnable else 16)
     cfg = dict(V=9600, d=256, h=4, N=4, L=L, learnable=learnable)

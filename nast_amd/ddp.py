@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 
 _reducers = []
+ENABLED = True      # set False to build a model that takes no part in the process group (tests: single-process reference)
 
 
 def _listener(p):
@@ -48,7 +49,7 @@ class GradReducer:
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.group = group
         self.bucket_bytes = bucket_bytes
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = ENABLED and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.armed = False
         self.plans = {}

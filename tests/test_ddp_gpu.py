@@ -1,0 +1,107 @@
+"""GPU: data-parallel f_step / d_step == single-process step on the concatenated batch.
+Two ranks share the one GPU of the test box and exchange gradients over gloo (RCCL needs one GPU per rank; the
+reducer code path -- arming, in-place gradient notifications, bucket launches, write-back -- is the same)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from helpers import make_param, synth_batch
+import nast_amd.utils as U
+from nast_amd.seq2seq import Seq2seq
+from nast_amd.utils import Storage
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+learnable = sys.argv[2] == "learnable"
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg = dict(V=48, d=32, h=4, N=2, L=8, learnable=learnable, gen_approx_mode="soft", dis_approx_mode="soft")
+U.cuda_init(0, "cuda")
+
+
+def build():
+    torch.manual_seed(0); np.random.seed(0)
+    m = Seq2seq(make_param(device="cuda", **cfg))
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, p in m.net.named_parameters():
+            if n.endswith("embed.weight"):
+                p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * 0.3).cuda())
+    m.net.model_F.train(); m.net.model_D.train()
+    return m
+
+
+def incoming(sent, slen, dom):
+    inc = Storage(); inc.data = Storage()
+    inc.data.sent, inc.data.sent_length, inc.data.domain = sent.cuda(), slen.cuda(), dom.cuda()
+    return inc
+
+
+dp = build()                      # reducers are live: the process group exists
+rng = np.random.default_rng(3)
+B = 4 * world
+for step in range(3):
+    sent, slen = synth_batch(rng, B, cfg["L"], cfg["V"])
+    dom = torch.tensor(([0, 0, 1, 1]) * world)
+    sl = slice(4 * rank, 4 * rank + 4)
+    # no input noise (identity NoiseLayer) so that the shards see exactly the rows of the full batch
+    ident = lambda w, l, rev_domain: (w, l)
+    dp.net.noiseLayer.forward = ident
+    # approx mode "soft" (seq2seq.py:409): no Gumbel draw, so shards and the full batch see the same soft tokens
+    if step < 2:
+        out = dp.f_step(incoming(sent[sl], slen[sl], dom[sl]), 1.0, use_inference_z=True)
+    else:
+        out = dp.d_step(incoming(sent[sl], slen[sl], dom[sl]), 1.0, use_inference_z=True)
+    if rank == 0:
+        # reference: same weights before the step, whole batch, no process group involvement
+        if step == 0:
+            import nast_amd.ddp as ddp_mod
+            ddp_mod.ENABLED = False
+            ref = build()
+            ddp_mod.ENABLED = True
+            ref.net.noiseLayer.forward = ident
+        # (ref was built from the same seed, so it tracks dp step by step)
+        if step < 2:
+            ref.f_step(incoming(sent, slen, dom), 1.0, use_inference_z=True)
+        else:
+            ref.d_step(incoming(sent, slen, dom), 1.0, use_inference_z=True)
+        # compare the (averaged, clipped) gradients the optimiser consumed.  Weights are not compared directly: Adam turns
+        # the rounding noise of analytically-zero gradients (key biases: softmax is shift invariant) into +-lr updates.
+        group = "model_F." if step < 2 else "model_D."
+        pairs = [(n, p.grad, q.grad) for (n, p), (_, q) in zip(dp.net.named_parameters(), ref.net.named_parameters())
+                 if n.startswith(group) and q.grad is not None]
+        assert len(pairs) > 20 and all(g is not None for _, g, _ in pairs)
+        scale = max(q.abs().max().item() for _, _, q in pairs)
+        worst = max((g - q).abs().max().item() for _, g, q in pairs) / scale
+        assert worst < 1e-4, (step, worst)
+        big = [(n, p, q) for (n, p), (_, q) in zip(dp.net.named_parameters(), ref.net.named_parameters()) if "weight" in n and p.dim() == 2]
+        for n, p, q in big:
+            assert (p - q).abs().max().item() <= 2.5e-4 * (q.abs().max().item() + 1e-3), (step, n)
+        print("step", step, "max grad diff / max grad", worst, flush=True)
+    dist.barrier()
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+@pytest.mark.parametrize("mode", ["simple", "learnable"])
+def test_two_rank_step_equals_single_process(tmp_path, mode):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    port = "29621" if mode == "simple" else "29622"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, mode], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
