@@ -186,9 +186,10 @@ def main():
         also = {"bs64": {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_small}}
 
     roofline = None
-    if rank == 0 and not a.no_roofline:
+    if not a.no_roofline:
         # second pass over the same steps with HIP-event timing armed around every launch of the dominant
-        # kernel family (grouped fp32 MFMA GEMM); kept out of the pass that produces `value`
+        # kernel family (grouped fp32 MFMA GEMM); kept out of the pass that produces `value`.  EVERY rank runs
+        # the steps (they contain the gradient all-reduce); rank 0 reports its own kernels.
         from nast_amd import _lib
         lib = _lib.load()
         lib.nast_prof_begin(1)
@@ -196,7 +197,7 @@ def main():
         torch.cuda.synchronize()
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         lib.nast_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
-        if ms.value > 0:
+        if rank == 0 and ms.value > 0:
             ach = fl.value / (ms.value * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "nast_gemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
