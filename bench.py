@@ -33,6 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # algorithmic GFLOP per sentence of one f_step (SURVEY.md section 8d / BASELINE.md section 3)
 GFLOP_PER_SENTENCE = {("learnable", 32): 10.1, ("learnable", 16): 5.12, ("simple", 16): 3.80}
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable by a float4 copy)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
 
 
@@ -185,6 +186,27 @@ def main():
         dt = (time.perf_counter() - t1) / n_small
         also = {"bs64": {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_small}}
 
+        def timed(fn, n):
+            for _ in range(2):
+                fn(0)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+
+        # the discriminator step (seq2seq.py:551-642) on the same batches
+        dt = timed(lambda i: model.d_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
+        also["d_step"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B}
+        # BASELINE.json configs[1]: simple alignment, YELP-shaped batch (64 sentences, len <= 16)
+        cfg1 = dict(V=9600, d=256, h=4, N=4, L=16, learnable=False)
+        m1 = build_model(cfg1, "cuda")
+        b1 = [synth_incoming(64, 16, 9600, 7000 + i, "cuda") for i in range(4)]
+        dt = timed(lambda i: m1.f_step(b1[i % 4], 1.0, use_inference_z=True), min(a.steps, 10))
+        also["configs1_simple_L16_bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3)}
+        del m1
+
     roofline = None
     if not a.no_roofline:
         # second pass over the same steps with HIP-event timing armed around every launch of the dominant
@@ -192,7 +214,7 @@ def main():
         # the steps (they contain the gradient all-reduce); rank 0 reports its own kernels.
         from nast_amd import _lib
         lib = _lib.load()
-        lib.nast_prof_begin(1)
+        lib.nast_prof_begin(0)        # every family: 1 GEMM, 2 vocabulary row kernels, 3 alignment DP
         run(min(a.steps, 5), offset=a.warmup)
         torch.cuda.synchronize()
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
@@ -203,6 +225,15 @@ def main():
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                         "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
                         "avg_launch_gflop": round(fl.value / max(n.value, 1) / 1e9, 4)}
+            # the HBM-bound families next to it: algorithmic bytes / HIP-event time
+            hbm = {}
+            for kind, name in ((2, "vocab_row_kernels"), (3, "alignment_dp")):
+                lib.nast_prof_get(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+                if ms.value > 0:
+                    gbs = fl.value / (ms.value * 1e-3) / 1e9
+                    hbm[name] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                 "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2)}
+            roofline["hbm_bound_kernels"] = hbm
     if world > 1:
         dist.barrier()
 

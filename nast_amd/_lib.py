@@ -80,6 +80,7 @@ SIGNATURES = {
     "nast_multi_adam_f32": [c_fp] * 5 + [_i, c_fp] + [_f] * 8 + [c_fp],
     "nast_prof_begin": [_i],
     "nast_prof_end": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
+    "nast_prof_get": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
 }
 _RESTYPES = {"nast_last_error": C.c_char_p, "nast_lp_decode_workspace_bytes": C.c_int64}
 

@@ -320,6 +320,7 @@ extern "C" int nast_align_viterbi_f32(const float* cost0, const float* cost, con
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(cost0 && cost && origin_length && target_length && allpos, "nast_align_viterbi_f32: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
+  nast_prof_before(3, s);
   if (S <= 64) {
     const size_t lds = (size_t)T * 4 + (size_t)(T - 1) * S + 16;
     hipLaunchKernelGGL(nast_align_viterbi_kernel<true>, dim3(B), dim3(64), lds, s, cost0, cost, origin_length, target_length,
@@ -330,6 +331,7 @@ extern "C" int nast_align_viterbi_f32(const float* cost0, const float* cost, con
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(B), dim3(64), lds, s, cost0, cost, origin_length, target_length, allpos, T, S);
   }
+  nast_prof_after(3, s, (double)B * (4.0 * T * S + 4.0 * T + 8.0 * (T + 1) + 16.0));   // SURVEY 8d bytes per sentence
   NAST_CHECK_LAUNCH("nast_align_viterbi_f32");
   return NAST_OK;
 }

@@ -16,14 +16,19 @@ void nast_set_error(const char* fmt, ...) {
 extern "C" const char* nast_last_error(void) { return g_err; }
 extern "C" int nast_version(void) { return 100; }
 
-// ---- profiler: one (start, stop) event pair per armed launch -------------------------------
+// ---- profiler: one (start, stop) event pair per armed launch, per kernel family -------------
 namespace {
-struct Prof {
-  int kind = 0;
+constexpr int NKIND = 4;       // 1 = GEMM (work = FLOP), 2 = vocabulary row kernels (work = algorithmic bytes), 3 = alignment DP (bytes)
+struct Fam {
   std::vector<hipEvent_t> ev;   // pairs
-  std::vector<hipEvent_t> pool;
-  double flops = 0;
+  double work = 0;
   int64_t launches = 0;
+  double ms = 0;
+};
+struct Prof {
+  unsigned mask = 0;
+  Fam fam[NKIND];
+  std::vector<hipEvent_t> pool;
 } g_prof;
 
 hipEvent_t get_event() {
@@ -36,45 +41,62 @@ hipEvent_t get_event() {
   hipEventCreate(&e);
   return e;
 }
+inline bool armed(int kind) { return kind > 0 && kind < NKIND && (g_prof.mask & (1u << kind)); }
 }  // namespace
 
 void nast_prof_before(int kind, hipStream_t s) {
-  if (g_prof.kind != kind) return;
+  if (!armed(kind)) return;
   hipEvent_t e = get_event();
   hipEventRecord(e, s);
-  g_prof.ev.push_back(e);
+  g_prof.fam[kind].ev.push_back(e);
 }
 
-void nast_prof_after(int kind, hipStream_t s, double flops) {
-  if (g_prof.kind != kind) return;
+void nast_prof_after(int kind, hipStream_t s, double work) {
+  if (!armed(kind)) return;
   hipEvent_t e = get_event();
   hipEventRecord(e, s);
-  g_prof.ev.push_back(e);
-  g_prof.flops += flops;
-  g_prof.launches += 1;
+  g_prof.fam[kind].ev.push_back(e);
+  g_prof.fam[kind].work += work;
+  g_prof.fam[kind].launches += 1;
 }
 
 extern "C" int nast_prof_begin(int kind) {
-  g_prof.kind = kind;
-  g_prof.flops = 0;
-  g_prof.launches = 0;
-  for (hipEvent_t e : g_prof.ev) g_prof.pool.push_back(e);
-  g_prof.ev.clear();
+  g_prof.mask = kind == 0 ? 0xEu : (1u << kind);   // 0 = every family
+  for (int k = 0; k < NKIND; ++k) {
+    Fam& f = g_prof.fam[k];
+    for (hipEvent_t e : f.ev) g_prof.pool.push_back(e);
+    f.ev.clear();
+    f.work = 0; f.launches = 0; f.ms = 0;
+  }
   return NAST_OK;
 }
 
-extern "C" int nast_prof_end(double* total_ms, double* total_flops, int64_t* launches) {
-  g_prof.kind = 0;
-  double ms = 0;
-  for (size_t i = 0; i + 1 < g_prof.ev.size(); i += 2) {
-    hipEventSynchronize(g_prof.ev[i + 1]);
-    float t = 0;
-    if (hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]) == hipSuccess) ms += t;
+static void prof_collect() {
+  g_prof.mask = 0;
+  for (int k = 0; k < NKIND; ++k) {
+    Fam& f = g_prof.fam[k];
+    for (size_t i = 0; i + 1 < f.ev.size(); i += 2) {
+      hipEventSynchronize(f.ev[i + 1]);
+      float t = 0;
+      if (hipEventElapsedTime(&t, f.ev[i], f.ev[i + 1]) == hipSuccess) f.ms += t;
+    }
+    for (hipEvent_t e : f.ev) g_prof.pool.push_back(e);
+    f.ev.clear();
   }
-  for (hipEvent_t e : g_prof.ev) g_prof.pool.push_back(e);
-  g_prof.ev.clear();
-  if (total_ms) *total_ms = ms;
-  if (total_flops) *total_flops = g_prof.flops;
-  if (launches) *launches = g_prof.launches;
+}
+
+extern "C" int nast_prof_end(double* total_ms, double* total_flops, int64_t* launches) {
+  prof_collect();
+  if (total_ms) *total_ms = g_prof.fam[1].ms;
+  if (total_flops) *total_flops = g_prof.fam[1].work;
+  if (launches) *launches = g_prof.fam[1].launches;
+  return NAST_OK;
+}
+
+extern "C" int nast_prof_get(int kind, double* total_ms, double* total_work, int64_t* launches) {
+  if (kind <= 0 || kind >= NKIND) return NAST_EINVAL;
+  if (total_ms) *total_ms = g_prof.fam[kind].ms;
+  if (total_work) *total_work = g_prof.fam[kind].work;
+  if (launches) *launches = g_prof.fam[kind].launches;
   return NAST_OK;
 }

@@ -302,7 +302,9 @@ extern "C" int nast_log_softmax_fwd_f32(const float* x, nast_rows xr, float* y, 
   NAST_REQUIRE(inv_temp > 0.f, "nast_log_softmax_fwd_f32: temperature must be > 0");
   if (rows == 0) return NAST_OK;
   NAST_REQUIRE(x && y && rows_ok(xr, V) && rows_ok(yr, V), "nast_log_softmax_fwd_f32: bad pointer/stride");
+  nast_prof_before(2, (hipStream_t)stream);
   hipLaunchKernelGGL(nast_log_softmax_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, xr, y, yr, V, inv_temp);
+  nast_prof_after(2, (hipStream_t)stream, 8.0 * rows * (double)V);
   NAST_CHECK_LAUNCH("nast_log_softmax_fwd_f32");
   return NAST_OK;
 }
@@ -312,8 +314,10 @@ extern "C" int nast_log_softmax_bwd_f32(const float* gy, nast_rows gyr, const fl
   NAST_REQUIRE(rows >= 0 && V >= 1, "nast_log_softmax_bwd_f32: bad sizes");
   if (rows == 0) return NAST_OK;
   NAST_REQUIRE(gy && y && gx, "nast_log_softmax_bwd_f32: NULL pointer");
+  nast_prof_before(2, (hipStream_t)stream);
   hipLaunchKernelGGL(nast_log_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, gy, gyr, y, yr, gx, gxr, V,
                      inv_temp);
+  nast_prof_after(2, (hipStream_t)stream, 12.0 * rows * (double)V);
   NAST_CHECK_LAUNCH("nast_log_softmax_bwd_f32");
   return NAST_OK;
 }
@@ -326,8 +330,10 @@ extern "C" int nast_gumbel_softmax_fwd_f32(const float* logits, nast_rows lr, co
   if (rows == 0) return NAST_OK;
   NAST_REQUIRE(logits && y, "nast_gumbel_softmax_fwd_f32: NULL pointer");
   NAST_REQUIRE(logits != y, "nast_gumbel_softmax_fwd_f32: in-place not supported");
+  nast_prof_before(2, (hipStream_t)stream);
   hipLaunchKernelGGL(nast_gumbel_softmax_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, lr, E, er, mask, y,
                      yr, idx, V, inv_tau, seed, offset, noise_off);
+  nast_prof_after(2, (hipStream_t)stream, (E ? 12.0 : 8.0) * rows * (double)V);
   NAST_CHECK_LAUNCH("nast_gumbel_softmax_fwd_f32");
   return NAST_OK;
 }
@@ -337,7 +343,9 @@ extern "C" int nast_softmax_bwd_f32(const float* gy, nast_rows gyr, const float*
   NAST_REQUIRE(rows >= 0 && V >= 1, "nast_softmax_bwd_f32: bad sizes");
   if (rows == 0) return NAST_OK;
   NAST_REQUIRE(gy && y && gx, "nast_softmax_bwd_f32: NULL pointer");
+  nast_prof_before(2, (hipStream_t)stream);
   hipLaunchKernelGGL(nast_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, gy, gyr, y, yr, gx, gxr, V, inv_tau);
+  nast_prof_after(2, (hipStream_t)stream, 12.0 * rows * (double)V);
   NAST_CHECK_LAUNCH("nast_softmax_bwd_f32");
   return NAST_OK;
 }
@@ -365,7 +373,9 @@ extern "C" int nast_nll_log_softmax_bwd_f32(const float* g, const float* y, nast
   NAST_REQUIRE(rows >= 0 && V >= 1, "nast_nll_log_softmax_bwd_f32: bad sizes");
   if (rows == 0) return NAST_OK;
   NAST_REQUIRE(g && y && tokens && gx, "nast_nll_log_softmax_bwd_f32: NULL pointer");
+  nast_prof_before(2, (hipStream_t)stream);
   hipLaunchKernelGGL(nast_nll_log_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, y, yr, tokens, gx, gxr, V, inv_temp);
+  nast_prof_after(2, (hipStream_t)stream, 8.0 * rows * (double)V);
   NAST_CHECK_LAUNCH("nast_nll_log_softmax_bwd_f32");
   return NAST_OK;
 }

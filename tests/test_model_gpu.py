@@ -253,3 +253,51 @@ def test_training_steps_golden(tag, mode):
                 np.testing.assert_allclose(w, v, rtol=0, atol=2.5e-4, err_msg=k)
             else:
                 np.testing.assert_allclose(w, v, rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+def _oracle_vs_hip_step(cfg, B, seed=0):
+    """One learnable f_step on fresh weights: HIP path vs the CPU oracle on identical weights, batch and Gumbel draw."""
+    import nast_amd.utils as U
+    from nast_amd.seq2seq import Seq2seq
+    from nast_amd.utils import Storage
+    from oracle import nast_oracle as O
+    from helpers import synth_batch
+    torch.manual_seed(seed); np.random.seed(seed)
+    U.cuda_init(0, "cuda")
+    model = Seq2seq(make_param(device="cuda", **cfg))
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in model.net.named_parameters():
+            if n.endswith("embed.weight"):     # the reference's all-zero embedding init makes every alignment tie
+                p.copy_(((torch.rand(p.shape, generator=gen) * 2 - 1) * (6.0 / sum(p.shape)) ** 0.5).cuda())
+    weights = {k: v.detach().cpu().clone() for k, v in model.net.state_dict().items() if k.startswith("model_")}
+    rng = np.random.default_rng(seed)
+    sent, slen = synth_batch(rng, B, cfg["L"], cfg["V"])
+    dom = torch.tensor([0] * (B // 2) + [1] * (B - B // 2))
+    inc = Storage(); inc.data = Storage()
+    inc.data.sent, inc.data.sent_length, inc.data.domain = sent.cuda(), slen.cuda(), dom.cuda()
+    model.net.noiseLayer.forward = lambda w, l, rev_domain: (w, l)          # identity noise: same input on both sides
+    model.net.model_F.train(); model.net.model_D.train()
+    tr = O.Trainer(weights, O.Cfg(**cfg))
+    with torch.no_grad():
+        gen_lp = O.style_transformer(tr.w, tr.cfg, sent, slen, None, None, 1 - dom, True, 1.0, True)[0]
+    E = torch.empty_like(gen_lp).exponential_(generator=gen)
+    ref = tr.f_step(sent, slen, dom, sent, slen, [E])
+    with U.inject_noise([E.cuda()]):
+        got = model.f_step(inc, 1.0, use_inference_z=True)
+    return np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64), float(model.last_grad_norm), float(tr.last_norm)
+
+
+def test_stress_shape_step_vs_oracle():
+    """BASELINE.json configs[4] shape at reduced depth/batch: d=1024, 16 heads, L=128 (129-token attention: the LDS
+    kernels), V=32000, 4d=4096 FFN -- every kernel family beyond its d=256 / L<=32 tuning point, fp32, 1e-3 on the losses."""
+    got, ref, gn, gn_ref = _oracle_vs_hip_step(dict(V=32000, d=1024, h=16, N=2, L=128, learnable=True), B=2)
+    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(gn, gn_ref, rtol=1e-3)
+
+
+def test_bench_shape_step_vs_oracle():
+    """The benchmark model (d=256, h=4, 4 layers, L=32, V=9600) at a small batch against the oracle."""
+    got, ref, gn, gn_ref = _oracle_vs_hip_step(dict(V=9600, d=256, h=4, N=4, L=32, learnable=True), B=6)
+    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(gn, gn_ref, rtol=1e-3)

@@ -44,6 +44,9 @@ static nast_gemm_desc mk(const float* A, const float* B, float* C, int M, int N,
 }
 
 static const char* g_filter = nullptr;
+static const float *g_x = nullptr, *g_y2 = nullptr;
+static float* g_y = nullptr;
+static size_t g_rot_stride = 0;
 static void run(const char* name, std::vector<nast_gemm_desc> g, int iters = 20) {
   if (g_filter && !strstr(name, g_filter)) return;
   double fl = 0;
@@ -54,7 +57,23 @@ static void run(const char* name, std::vector<nast_gemm_desc> g, int iters = 20)
     if (nast_gemm_f32(g.data(), (int)g.size(), nullptr) != 0) { printf("%s: ERROR %s\n", name, nast_last_error()); return; }
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(a, nullptr));
-  for (int i = 0; i < iters; ++i) nast_gemm_f32(g.data(), (int)g.size(), nullptr);
+  // GB_ROT=n: rotate the A operands / outputs through n copies spaced `g_rot_stride` floats apart, so that no launch
+  // finds its activations in L2 (what a training step looks like: every GEMM reads tensors written by other kernels)
+  static const int rot = getenv("GB_ROT") ? atoi(getenv("GB_ROT")) : 1;
+  for (int i = 0; i < iters; ++i) {
+    if (rot > 1) {
+      std::vector<nast_gemm_desc> h = g;
+      const size_t off = (size_t)(i % rot) * g_rot_stride;
+      for (auto& d : h) {
+        if (!d.transA && d.A[0] == g_x) d.A[0] += off;
+        if (d.residual == g_y2) d.residual += off;
+        if (d.C == g_y) d.C += off;
+      }
+      nast_gemm_f32(h.data(), (int)h.size(), nullptr);
+    } else {
+      nast_gemm_f32(g.data(), (int)g.size(), nullptr);
+    }
+  }
   CK(hipEventRecord(b, nullptr));
   CK(hipEventSynchronize(b));
   float ms = 0;
@@ -69,9 +88,11 @@ int main(int argc, char** argv) {
   if (argc > 1) g_filter = argv[1];   // substring filter on the case name
   for (int M : {2112, 16896}) {
     const int Mv = M == 2112 ? 2048 : 16384;
-    float* x = dalloc((size_t)M * ff);
-    float* y = dalloc((size_t)M * ff, false);
-    float* y2 = dalloc((size_t)M * ff, false);
+    const int rotn = getenv("GB_ROT") ? atoi(getenv("GB_ROT")) : 1;
+    float* x = dalloc((size_t)M * ff * rotn);
+    float* y = dalloc((size_t)M * ff * rotn, false);
+    float* y2 = dalloc((size_t)M * ff * rotn, false);
+    g_x = x; g_y = y; g_y2 = y2; g_rot_stride = (size_t)M * ff;
     float* y3 = dalloc((size_t)M * ff, false);
     float* W = dalloc((size_t)ff * d);
     float* W2 = dalloc((size_t)ff * d);
