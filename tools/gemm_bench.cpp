@@ -105,6 +105,20 @@ int main(int argc, char** argv) {
     float* dE = dalloc((size_t)V * d, false);
     char nm[128];
     auto N = [&](const char* s) { snprintf(nm, sizeof(nm), "M=%d %s", M, s); return nm; };
+    for (int Ms : {64, 512}) {    // greedy-decode shapes (small-M path), with and without the fused LayerNorm
+      char nm2[128];
+      nast_gemm_desc q = mk(x, W, y, Ms, d, d, d, d, d, 0, 1);
+      q.bias = W3;
+      snprintf(nm2, sizeof(nm2), "M=%d decode Ms=%d d->d", M, Ms); run(nm2, {q}, 50);
+      nast_gemm_desc q2 = q; q2.ln_gamma = W2; q2.ln_beta = W3;
+      snprintf(nm2, sizeof(nm2), "M=%d decode Ms=%d LN+d->d", M, Ms); run(nm2, {q2}, 50);
+      nast_gemm_desc k2 = q2, v2 = q2; k2.C = y2; v2.C = y3;
+      snprintf(nm2, sizeof(nm2), "M=%d decode Ms=%d LN+QKV x3", M, Ms); run(nm2, {q2, k2, v2}, 50);
+      nast_gemm_desc f1 = mk(x, W, y, Ms, ff, d, d, d, ff, 0, 1); f1.ln_gamma = W2; f1.ln_beta = W3; f1.flags = NAST_GEMM_RELU;
+      snprintf(nm2, sizeof(nm2), "M=%d decode Ms=%d LN+d->4d relu", M, Ms); run(nm2, {f1}, 50);
+      nast_gemm_desc f2 = mk(x, W, y, Ms, d, ff, ff, ff, d, 0, 1); f2.residual = y2;
+      snprintf(nm2, sizeof(nm2), "M=%d decode Ms=%d 4d->d + res", M, Ms); run(nm2, {f2}, 50);
+    }
     // forward: y = x W^T
     run(N("fwd  d->d"), {mk(x, W, y, M, d, d, d, d, d, 0, 1)});
     {
