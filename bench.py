@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="GEMM arithmetic: fp32 MFMA (reference dtype, default) or the bf16-MFMA variant")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,6 +147,8 @@ def main():
     cfg = dict(V=9600, d=256, h=4, N=4, L=L, learnable=learnable)
     B = a.batch_per_gpu
     model = build_model(cfg, "cuda")
+    from nast_amd import ops as _ops
+    _ops.set_gemm_precision(a.precision)
     # every rank holds different sentences (its shard of the global batch) and identical weights
     batches = [synth_incoming(B, L, cfg["V"], 1000 * rank + i, "cuda") for i in range(4)]
     np.random.seed(100 + rank)
@@ -206,6 +210,13 @@ def main():
         dt = timed(lambda i: m1.f_step(b1[i % 4], 1.0, use_inference_z=True), min(a.steps, 10))
         also["configs1_simple_L16_bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3)}
         del m1
+        if a.precision == "fp32":
+            # north_star's bf16 variant: GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 storage + accumulate), same step
+            _ops.set_gemm_precision("bf16")
+            dt = timed(lambda i: model.f_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
+            _ops.set_gemm_precision("fp32")
+            also["bf16_gemm_variant"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B,
+                                         "dtype": "bf16 MFMA operands, fp32 accumulate/storage"}
 
     roofline = None
     if not a.no_roofline:
@@ -244,7 +255,7 @@ def main():
             "metric": "train sentences/sec (fwd+bwd, NAST-StyTrans learnable)" if learnable else "train sentences/sec (fwd+bwd, NAST-StyTrans simple)",
             "value": round(sps, 2), "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if a.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"NAST-StyTrans f_step, {a.alignment} alignment, len<={L}, vocab 9600, d=256, h=4, 4 layers, "
                                    f"{B} sentences/GPU (BASELINE configs[{'2] at the per-GPU batch of configs[3' if learnable else '1'}])",
                        "global_batch": B * world, "max_length": L, "parallelism": f"dp{world}"},

@@ -42,6 +42,8 @@ int nast_version(void);
 #define NAST_GEMM_RELU 1        /* C = max(C, 0) after bias/residual                                 */
 #define NAST_GEMM_ATOMIC 2      /* C += result with fp32 atomics (C pre-initialised); enables split-K */
 #define NAST_GEMM_ACCUM 4       /* C += result, non-atomic (single writer, no split-K)               */
+#define NAST_GEMM_BF16 8        /* bf16 variant: operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16, fp32 accumulate; */
+                                /* storage stays fp32.  Applies when every problem of the launch sets it (else fp32).            */
 
 typedef struct nast_gemm_desc {
   const float* A[NAST_GEMM_MAX_SRC]; /* op(A) is M x K.  transA=0: A stored [M, lda>=K]; transA=1: [K, lda>=M] */

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnast_hip.so")
 
 GEMM_MAX_GROUP = 8
 GEMM_MAX_SRC = 3
-GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM = 1, 2, 4
+GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, GEMM_BF16 = 1, 2, 4, 8
 
 c_fp = C.c_void_p   # all device pointers travel as void*
 

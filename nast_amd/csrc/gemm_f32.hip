@@ -19,6 +19,13 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NAST_GEMM_VEC_C (1 << 16)   // internal: C / bias / residual / relu_src allow 16-B accesses
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 pack_bf16(const float4& lo, const float4& hi) {
+  bf16x8 r;
+  r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
+  r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
+  return r;
+}
 #ifndef NAST_BK128
 #define NAST_BK128 32
 #endif
@@ -130,7 +137,7 @@ __device__ __forceinline__ float4 frag_read(const float* __restrict__ lds, int r
 
 // One output tile (and K slice) of one problem; operand layouts are compile-time so that the K loop is
 // branch-free: all fragment reads of a K-tile are issued first, then the MFMAs run back to back.
-template <int BM, int BN, int BK, bool AKC, bool BKC, bool FAST>
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool FAST, bool BF16>
 __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int tn, int kz, int kt_per_split, float* smem) {
   using GA = TileGeom<BM, BK>;
   using GB = TileGeom<BN, BK>;
@@ -219,6 +226,39 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
         for (int k = 0; k < KP; ++k) colacc += As[(k0c + k) * GA::MC_LD + cm];
       }
     }
+    if constexpr (BF16) {
+      // bf16 variant (north_star: "bf16 variant within 2e-2"): same fp32 LDS images and the same fragment reads; two
+      // 8-wide k-groups (lane half h: k = 16 t + 4 h + s and 16 t + 8 + 4 h + s) are rounded to bf16 in registers and
+      // feed ONE v_mfma_f32_32x32x16_bf16 (fp32 accumulate) -- A and B share the k assignment, so the product is exact
+      // in its pairing.  16x the matrix rate of the fp32 instruction: the kernel becomes load-bound.
+#pragma unroll
+      for (int t = 0; t < NG / 2; ++t) {
+        if (t > 0) {
+#pragma unroll
+          for (int a = 0; a < MT; ++a) fa[0][a] = frag_read<BM, BK, AKC>(As, wm * WTM + a * 32 + li, 2 * t, lh);
+#pragma unroll
+          for (int b = 0; b < NT; ++b) fb[0][b] = frag_read<BN, BK, BKC>(Bs, wn * WTN + b * 32 + li, 2 * t, lh);
+        }
+#pragma unroll
+        for (int a = 0; a < MT; ++a) fa[1][a] = frag_read<BM, BK, AKC>(As, wm * WTM + a * 32 + li, 2 * t + 1, lh);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) fb[1][b] = frag_read<BN, BK, BKC>(Bs, wn * WTN + b * 32 + li, 2 * t + 1, lh);
+        if (t == 0 && step + 1 < steps) {
+          float* An = smem + (cur ^ 1) * (GA::SZ + GB::SZ);
+          tile_store<BM, BK, AKC>(An, ra);
+          tile_store<BN, BK, BKC>(An + GA::SZ, rb);
+        }
+        bf16x8 a8[MT], b8[NT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) a8[a] = pack_bf16(fa[0][a], fa[1][a]);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) b8[b] = pack_bf16(fb[0][b], fb[1][b]);
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[a], b8[b], acc[a][b], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int c = g & 1, n = c ^ 1;
@@ -252,6 +292,7 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][a].w, fb[c][b].w, acc[a][b], 0, 0, 0);
+    }
     }
     __syncthreads();
   }
@@ -359,7 +400,7 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
     }
 }
 
-template <int BM, int BN, int BK, bool FAST>
+template <int BM, int BN, int BK, bool FAST, bool BF16>
 __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) {
   using GA = TileGeom<BM, BK>;
   using GB = TileGeom<BN, BK>;
@@ -384,10 +425,10 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
   const int kz = tq / P.tiles_m[gi];
   const int per = P.kt_per_split[gi];
   const bool a_kc = (D.transA == 0), b_kc = (D.transB != 0);
-  if (a_kc && b_kc) gemm_tile<BM, BN, BK, true, true, FAST>(D, tm, tn, kz, per, smem);          // y = x W^T
-  else if (a_kc && !b_kc) gemm_tile<BM, BN, BK, true, false, FAST>(D, tm, tn, kz, per, smem);   // dx = dy W, soft x E
-  else if (!a_kc && !b_kc) gemm_tile<BM, BN, BK, false, false, FAST>(D, tm, tn, kz, per, smem); // dW = dy^T x
-  else gemm_tile<BM, BN, BK, false, true, FAST>(D, tm, tn, kz, per, smem);
+  if (a_kc && b_kc) gemm_tile<BM, BN, BK, true, true, FAST, BF16>(D, tm, tn, kz, per, smem);          // y = x W^T
+  else if (a_kc && !b_kc) gemm_tile<BM, BN, BK, true, false, FAST, BF16>(D, tm, tn, kz, per, smem);   // dx = dy W, soft x E
+  else if (!a_kc && !b_kc) gemm_tile<BM, BN, BK, false, false, FAST, BF16>(D, tm, tn, kz, per, smem); // dW = dy^T x
+  else gemm_tile<BM, BN, BK, false, true, FAST, BF16>(D, tm, tn, kz, per, smem);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -637,10 +678,14 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
   P.xcd_order = xcd_order;
   for (int i = count; i <= NAST_GEMM_MAX_GROUP; ++i) P.tile_start[i] = start;
   if (start == 0) return 0;
-  if (fast_ok<BM, BN, BK>(descs, count))
-    hipLaunchKernelGGL((nast_gemm_f32_kernel<BM, BN, BK, true>), dim3(start), dim3(256), 0, stream, P);
-  else
-    hipLaunchKernelGGL((nast_gemm_f32_kernel<BM, BN, BK, false>), dim3(start), dim3(256), 0, stream, P);
+  bool bf16 = true;
+  for (int i = 0; i < count; ++i) bf16 = bf16 && (descs[i].flags & NAST_GEMM_BF16);
+  if (fast_ok<BM, BN, BK>(descs, count)) {
+    if (bf16) hipLaunchKernelGGL((nast_gemm_f32_kernel<BM, BN, BK, true, true>), dim3(start), dim3(256), 0, stream, P);
+    else hipLaunchKernelGGL((nast_gemm_f32_kernel<BM, BN, BK, true, false>), dim3(start), dim3(256), 0, stream, P);
+  } else {   // odd shapes / alignments: the general fp32 kernel (also for bf16 requests: more precise, never less)
+    hipLaunchKernelGGL((nast_gemm_f32_kernel<BM, BN, BK, false, false>), dim3(start), dim3(256), 0, stream, P);
+  }
   return 0;
 }
 

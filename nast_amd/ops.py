@@ -10,7 +10,9 @@ import math
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, Rows, GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, call
+import contextlib
+
+from ._lib import GemmDesc, Rows, GEMM_RELU, GEMM_ATOMIC, GEMM_ACCUM, GEMM_BF16, call
 
 F32 = torch.float32
 
@@ -44,6 +46,30 @@ def _flat_rows(n_rows, ld):
     return Rows(ld, 0, 0)
 
 
+# GEMM precision of the module-level path: "fp32" (v_mfma_f32_32x32x2_f32, the reference's dtype and the default) or
+# "bf16" (operands rounded to bf16 in registers, v_mfma_f32_32x32x16_bf16, fp32 accumulate; LayerNorm, softmax,
+# attention, log-sum-exp statistics and the alignment DP stay fp32 -- north_star's "bf16 variant within 2e-2").
+_GEMM_FLAGS = 0
+
+
+def set_gemm_precision(name):
+    global _GEMM_FLAGS
+    if name not in ("fp32", "bf16"):
+        raise ValueError("gemm precision must be 'fp32' or 'bf16'")
+    _GEMM_FLAGS = GEMM_BF16 if name == "bf16" else 0
+
+
+@contextlib.contextmanager
+def gemm_precision(name):
+    global _GEMM_FLAGS
+    saved = _GEMM_FLAGS
+    set_gemm_precision(name)
+    try:
+        yield
+    finally:
+        _GEMM_FLAGS = saved
+
+
 def desc(A, B, Cm, M, N, K, lda, ldb, ldc, transA, transB, bias=None, residual=None, relu_src=None, colsum=None,
          flags=0, alpha=1.0):
     """Build one nast_gemm_desc. A / B may be a tensor or a list of up to 3 tensors (summed products)."""
@@ -62,7 +88,7 @@ def desc(A, B, Cm, M, N, K, lda, ldb, ldc, transA, transB, bias=None, residual=N
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
     d.transA, d.transB = transA, transB
-    d.flags = flags
+    d.flags = flags | _GEMM_FLAGS
     d.alpha = alpha
     return d
 

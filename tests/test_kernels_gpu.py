@@ -320,3 +320,36 @@ def test_generator_nll_fused(ops, rows, d, V, temp):
     out = ops.generator_nll(gx, gW, gb, temp, dev(tok))
     (out * dev(w)).sum().backward()
     relclose(out, ref); relclose(gx.grad, rx.grad); relclose(gW.grad, rW.grad); relclose(gb.grad, rb.grad)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 64, 64), (1088, 256, 256), (300, 1024, 256), (2112, 9600, 256)])
+def test_gemm_bf16_variant(ops, M, N, K):
+    """bf16-MFMA variant of the grouped GEMM (fp32 storage, fp32 accumulate): forward, dgrad, wgrad, bias grad within the
+    bf16 tolerance of north_star (2e-2 relative to the largest element)."""
+    g = torch.Generator().manual_seed(M + N)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    rx, rW, rb = (t.clone().requires_grad_(True) for t in (x, W, b))
+    ref = torch.nn.functional.linear(rx, rW, rb)
+    (ref * R).sum().backward()
+    gx, gW, gb = (dev(t).requires_grad_(True) for t in (x, W, b))
+    with ops.gemm_precision("bf16"):
+        y = ops.linear(gx, gW, gb)
+        (y * dev(R)).sum().backward()
+    for a, r in ((y, ref), (gx.grad, rx.grad), (gW.grad, rW.grad), (gb.grad, rb.grad)):
+        relclose(a, r, 2e-2)
+    # and it really is a different arithmetic: not bit-identical to the fp32 path
+    y32 = ops.linear(dev(x), dev(W), dev(b))
+    if M > 1024:      # (M <= 1024 forward goes through the small-M kernel, which is fp32 only)
+        assert (y32 - y).abs().max().item() > 0
+    relclose(y32, ref, 1e-4)
+
+
+def test_step_bf16_variant_vs_oracle():
+    """One learnable f_step with bf16-MFMA GEMMs against the fp32 CPU oracle: losses within 2e-2."""
+    from test_model_gpu import _oracle_vs_hip_step
+    from nast_amd import ops as o
+    with o.gemm_precision("bf16"):
+        got, ref, gn, gn_ref = _oracle_vs_hip_step(dict(V=9600, d=256, h=4, N=4, L=32, learnable=True), B=6, seed=3)
+    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-3)
+    np.testing.assert_allclose(gn, gn_ref, rtol=5e-2)

@@ -49,6 +49,7 @@ static float* g_y = nullptr;
 static size_t g_rot_stride = 0;
 static void run(const char* name, std::vector<nast_gemm_desc> g, int iters = 20) {
   if (g_filter && !strstr(name, g_filter)) return;
+  if (getenv("GB_BF16")) for (auto& d : g) d.flags |= NAST_GEMM_BF16;
   double fl = 0;
   for (auto& d : g) fl += 2.0 * d.M * d.N * (double)d.K * d.nsrc;
   hipEvent_t a, b;
