@@ -289,6 +289,170 @@ __global__ void nast_first_eos_kernel(const int64_t* __restrict__ tok, int64_t* 
   len[b] = (n + 1 < L) ? n + 1 : L;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Register-resident variants for rows of V <= 256 * 4 * RR_NV floats (V % 4 == 0, 16-B aligned rows): the row is read
+// from HBM exactly once into <= RR_NV float4 per thread, reduced, and written exactly once -- the algorithmic 8V
+// (12V) bytes per row, no re-read of a 38 KB row through L2 between the passes.
+// ---------------------------------------------------------------------------------------------
+#define RR_NV 10
+
+__global__ __launch_bounds__(256) void nast_log_softmax_fwd_rr_kernel(const float* __restrict__ x, nast_rows xr,
+                                                                      float* __restrict__ y, nast_rows yr, int V, float it) {
+  __shared__ float red[4];
+  const int64_t r = blockIdx.x;
+  const float4* xp = reinterpret_cast<const float4*>(x + row_offset(r, xr));
+  float4* yp = reinterpret_cast<float4*>(y + row_offset(r, yr));
+  const int nvec = V >> 2;
+  float4 v[RR_NV];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < RR_NV; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nvec) {
+      float4 t = xp[c];
+      t.x *= it; t.y *= it; t.z *= it; t.w *= it;
+      v[i] = t;
+      m = fmaxf(fmaxf(m, fmaxf(t.x, t.y)), fmaxf(t.z, t.w));
+    }
+  }
+  m = block_max<256>(m, red);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < RR_NV; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nvec) s += __expf(v[i].x - m) + __expf(v[i].y - m) + __expf(v[i].z - m) + __expf(v[i].w - m);
+  }
+  s = block_sum<256>(s, red);
+  const float lz = m + __logf(s);
+#pragma unroll
+  for (int i = 0; i < RR_NV; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nvec) yp[c] = make_float4(v[i].x - lz, v[i].y - lz, v[i].z - lz, v[i].w - lz);
+  }
+}
+
+// gx = (gy - exp(y) * sum(gy)) * it      (LOGSM = true)       gx = y * (gy - sum(gy * y)) * it      (LOGSM = false)
+template <bool LOGSM>
+__global__ __launch_bounds__(256) void nast_softmax_bwd_rr_kernel(const float* __restrict__ gy, nast_rows gyr,
+                                                                  const float* __restrict__ y, nast_rows yr,
+                                                                  float* __restrict__ gx, nast_rows gxr, int V, float it) {
+  __shared__ float red[4];
+  const int64_t r = blockIdx.x;
+  const float4* gp = reinterpret_cast<const float4*>(gy + row_offset(r, gyr));
+  const float4* yp = reinterpret_cast<const float4*>(y + row_offset(r, yr));
+  float4* op = reinterpret_cast<float4*>(gx + row_offset(r, gxr));
+  const int nvec = V >> 2;
+  float4 g[RR_NV], p[RR_NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < RR_NV; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nvec) {
+      g[i] = gp[c];
+      p[i] = yp[c];
+      if (LOGSM) s += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      else s += (g[i].x * p[i].x + g[i].y * p[i].y) + (g[i].z * p[i].z + g[i].w * p[i].w);
+    }
+  }
+  s = block_sum<256>(s, red);
+#pragma unroll
+  for (int i = 0; i < RR_NV; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nvec) {
+      float4 o;
+      if (LOGSM) {
+        o.x = (g[i].x - __expf(p[i].x) * s) * it; o.y = (g[i].y - __expf(p[i].y) * s) * it;
+        o.z = (g[i].z - __expf(p[i].z) * s) * it; o.w = (g[i].w - __expf(p[i].w) * s) * it;
+      } else {
+        o.x = p[i].x * (g[i].x - s) * it; o.y = p[i].y * (g[i].y - s) * it;
+        o.z = p[i].z * (g[i].z - s) * it; o.w = p[i].w * (g[i].w - s) * it;
+      }
+      op[c] = o;
+    }
+  }
+}
+
+// Gumbel-softmax sample without a mask: z = (logit + g) * it kept in registers, one read (+ the noise), one write
+__global__ __launch_bounds__(256) void nast_gumbel_softmax_fwd_rr_kernel(const float* __restrict__ logits, nast_rows lr,
+                                                                         const float* __restrict__ E, nast_rows er,
+                                                                         float* __restrict__ y, nast_rows yr,
+                                                                         int64_t* __restrict__ idx, int V, float it, uint64_t seed,
+                                                                         uint64_t offset, int noise_off) {
+  __shared__ float red[4];
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const int64_t r = blockIdx.x;
+  const float4* lp = reinterpret_cast<const float4*>(logits + row_offset(r, lr));
+  const float4* ep = E ? reinterpret_cast<const float4*>(E + row_offset(r, er)) : nullptr;
+  float4* yp = reinterpret_cast<float4*>(y + row_offset(r, yr));
+  const int nvec = V >> 2;
+  float4 z[RR_NV];
+  Best best{-INFINITY, 0x7fffffff};
+#pragma unroll
+  for (int i = 0; i < RR_NV; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nvec) {
+      const float4 l = lp[c];
+      float g[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!noise_off) {
+        if (ep) {
+          const float4 e = ep[c];
+          g[0] = gumbel_of(e.x); g[1] = gumbel_of(e.y); g[2] = gumbel_of(e.z); g[3] = gumbel_of(e.w);
+        } else {
+          uint32_t rb[4];
+          const uint64_t ctr = (uint64_t)r * (uint64_t)((V + 3) / 4) + c;
+          philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                        (uint32_t)(seed >> 32), rb);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) g[u] = gumbel_of(exp1_from_bits(rb[u]));
+        }
+      }
+      z[i] = make_float4((l.x + g[0]) * it, (l.y + g[1]) * it, (l.z + g[2]) * it, (l.w + g[3]) * it);
+      best_upd(best, z[i].x, 4 * c); best_upd(best, z[i].y, 4 * c + 1);
+      best_upd(best, z[i].z, 4 * c + 2); best_upd(best, z[i].w, 4 * c + 3);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best.v, o, 64);
+    const int oi = __shfl_xor(best.i, o, 64);
+    best_upd(best, ov, oi);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    bv[w] = best.v;
+    bi[w] = best.i;
+  }
+  __syncthreads();
+  Best all{bv[0], bi[0]};
+#pragma unroll
+  for (int i = 1; i < 4; ++i) best_upd(all, bv[i], bi[i]);
+  const float m = all.v;
+  if (idx && threadIdx.x == 0) idx[r] = all.i;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < RR_NV; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nvec) {
+      z[i].x = __expf(z[i].x - m); z[i].y = __expf(z[i].y - m); z[i].z = __expf(z[i].z - m); z[i].w = __expf(z[i].w - m);
+      s += (z[i].x + z[i].y) + (z[i].z + z[i].w);
+    }
+  }
+  s = block_sum<256>(s, red);
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int i = 0; i < RR_NV; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nvec) yp[c] = make_float4(z[i].x * inv, z[i].y * inv, z[i].z * inv, z[i].w * inv);
+  }
+}
+
+static bool rr_rows_ok(const void* base, nast_rows a) {
+  return (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (a.ld & 3) == 0 && (a.grp_stride & 3) == 0;
+}
+static bool rr_ok(int V) { return (V & 3) == 0 && V <= 256 * 4 * RR_NV; }
+
 // ---------------------------------------------------------------------------------------------
 static bool rows_ok(nast_rows a, int V) {
   // vector path needs every row start 16-B aligned relative to the base; the kernels test the actual
@@ -303,7 +467,10 @@ extern "C" int nast_log_softmax_fwd_f32(const float* x, nast_rows xr, float* y, 
   if (rows == 0) return NAST_OK;
   NAST_REQUIRE(x && y && rows_ok(xr, V) && rows_ok(yr, V), "nast_log_softmax_fwd_f32: bad pointer/stride");
   nast_prof_before(2, (hipStream_t)stream);
-  hipLaunchKernelGGL(nast_log_softmax_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, xr, y, yr, V, inv_temp);
+  if (rr_ok(V) && rr_rows_ok(x, xr) && rr_rows_ok(y, yr))
+    hipLaunchKernelGGL(nast_log_softmax_fwd_rr_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, xr, y, yr, V, inv_temp);
+  else
+    hipLaunchKernelGGL(nast_log_softmax_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, xr, y, yr, V, inv_temp);
   nast_prof_after(2, (hipStream_t)stream, 8.0 * rows * (double)V);
   NAST_CHECK_LAUNCH("nast_log_softmax_fwd_f32");
   return NAST_OK;
@@ -315,8 +482,11 @@ extern "C" int nast_log_softmax_bwd_f32(const float* gy, nast_rows gyr, const fl
   if (rows == 0) return NAST_OK;
   NAST_REQUIRE(gy && y && gx, "nast_log_softmax_bwd_f32: NULL pointer");
   nast_prof_before(2, (hipStream_t)stream);
-  hipLaunchKernelGGL(nast_log_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, gy, gyr, y, yr, gx, gxr, V,
-                     inv_temp);
+  if (rr_ok(V) && rr_rows_ok(gy, gyr) && rr_rows_ok(y, yr) && rr_rows_ok(gx, gxr))
+    hipLaunchKernelGGL(nast_softmax_bwd_rr_kernel<true>, dim3(rows), dim3(256), 0, (hipStream_t)stream, gy, gyr, y, yr, gx, gxr, V, inv_temp);
+  else
+    hipLaunchKernelGGL(nast_log_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, gy, gyr, y, yr, gx, gxr, V,
+                       inv_temp);
   nast_prof_after(2, (hipStream_t)stream, 12.0 * rows * (double)V);
   NAST_CHECK_LAUNCH("nast_log_softmax_bwd_f32");
   return NAST_OK;
@@ -331,8 +501,12 @@ extern "C" int nast_gumbel_softmax_fwd_f32(const float* logits, nast_rows lr, co
   NAST_REQUIRE(logits && y, "nast_gumbel_softmax_fwd_f32: NULL pointer");
   NAST_REQUIRE(logits != y, "nast_gumbel_softmax_fwd_f32: in-place not supported");
   nast_prof_before(2, (hipStream_t)stream);
-  hipLaunchKernelGGL(nast_gumbel_softmax_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, lr, E, er, mask, y,
-                     yr, idx, V, inv_tau, seed, offset, noise_off);
+  if (!mask && rr_ok(V) && rr_rows_ok(logits, lr) && rr_rows_ok(y, yr) && (!E || rr_rows_ok(E, er)))
+    hipLaunchKernelGGL(nast_gumbel_softmax_fwd_rr_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, lr, E, er, y, yr, idx,
+                       V, inv_tau, seed, offset, noise_off);
+  else
+    hipLaunchKernelGGL(nast_gumbel_softmax_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, lr, E, er, mask, y,
+                       yr, idx, V, inv_tau, seed, offset, noise_off);
   nast_prof_after(2, (hipStream_t)stream, (E ? 12.0 : 8.0) * rows * (double)V);
   NAST_CHECK_LAUNCH("nast_gumbel_softmax_fwd_f32");
   return NAST_OK;
@@ -344,7 +518,10 @@ extern "C" int nast_softmax_bwd_f32(const float* gy, nast_rows gyr, const float*
   if (rows == 0) return NAST_OK;
   NAST_REQUIRE(gy && y && gx, "nast_softmax_bwd_f32: NULL pointer");
   nast_prof_before(2, (hipStream_t)stream);
-  hipLaunchKernelGGL(nast_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, gy, gyr, y, yr, gx, gxr, V, inv_tau);
+  if (rr_ok(V) && rr_rows_ok(gy, gyr) && rr_rows_ok(y, yr) && rr_rows_ok(gx, gxr))
+    hipLaunchKernelGGL(nast_softmax_bwd_rr_kernel<false>, dim3(rows), dim3(256), 0, (hipStream_t)stream, gy, gyr, y, yr, gx, gxr, V, inv_tau);
+  else
+    hipLaunchKernelGGL(nast_softmax_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, gy, gyr, y, yr, gx, gxr, V, inv_tau);
   nast_prof_after(2, (hipStream_t)stream, 12.0 * rows * (double)V);
   NAST_CHECK_LAUNCH("nast_softmax_bwd_f32");
   return NAST_OK;
