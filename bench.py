@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="serialise f_step's transfer pass instead of a second stream")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="GEMM arithmetic: fp32 MFMA (reference dtype, default) or the bf16-MFMA variant")
     a = ap.parse_args()
@@ -149,6 +150,7 @@ def main():
     model = build_model(cfg, "cuda")
     from nast_amd import ops as _ops
     _ops.set_gemm_precision(a.precision)
+    model.overlap_passes = not a.no_overlap
     # every rank holds different sentences (its shard of the global batch) and identical weights
     batches = [synth_incoming(B, L, cfg["V"], 1000 * rank + i, "cuda") for i in range(4)]
     np.random.seed(100 + rank)

@@ -37,6 +37,17 @@ class Seq2seq(BaseModel):
         self.reducer_F = GradReducer(list(self.net.model_F.parameters()))
         self.reducer_D = GradReducer(list(self.net.model_D.parameters()))
 
+    overlap_passes = True      # f_step: run the transfer pass on a second stream beside pass 1 (set False to serialise)
+    _streams = None
+
+    def _side_stream(self, device):
+        if self._streams is None:
+            self._streams = {}
+        key = (device.type, device.index)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
+
     # ---- batches (seq2seq.py:108-164) ---------------------------------------------------------
     def _preprocess_batch(self, data0, data1):
         incoming = Storage()
@@ -170,6 +181,15 @@ class Seq2seq(BaseModel):
         noise_inp_tokens = noise_inp_tokens.transpose(0, 1).contiguous()
 
         model_F = self.net.model_F
+        # The transfer pass (seq2seq.py:476-490) depends on nothing the self-reconstruction pass produces, and a large
+        # part of it is the greedy skip decoding: ~800 small dependent launches that leave most of the 256 CUs idle.
+        # It is therefore issued on a second HIP stream AFTER the whole first pass (forward + backward #1) has been
+        # enqueued on the main stream, so the GPU runs both at once; the streams join before the cycle pass.
+        overlap = self.overlap_passes and cyc_rec_enable and inp_tokens.is_cuda
+        if overlap:
+            main = torch.cuda.current_stream()
+            side = self._side_stream(inp_tokens.device)
+            side.wait_stream(main)          # inputs are ready; nothing of pass 1 is enqueued yet
         # nll_targets: Generator + NLLLoss(reduction='none') (seq2seq.py:453) run as one node on the device
         slf_nll, _, slf_length_losses, slf_gen_error, _ = model_F(
             noise_inp_tokens, noise_inp_lengths, inp_tokens, inp_lengths, raw_styles,
@@ -195,12 +215,23 @@ class Seq2seq(BaseModel):
             self.net.model_D.train()
             return slf_rec_loss.item(), 0, 0, item(slf_rec_length_loss), 0, item(slf_gen_error), 0
 
-        gen_log_probs, gen_lengths, _, _, _ = model_F(
-            inp_tokens, inp_lengths, None, None, rev_styles,
-            generate=True, differentiable_decode=True, temperature=temperature, use_inference_z=use_inference_z)
-        gen_soft_tokens, gen_idx = self._approx_with_index(gen_log_probs, args.gen_approx_mode)
-        if not args.use_learnable:
-            gen_lengths = self.get_lengths(gen_idx, eos_idx)
+        def transfer_pass():
+            glp, glen, _, _, _ = model_F(
+                inp_tokens, inp_lengths, None, None, rev_styles,
+                generate=True, differentiable_decode=True, temperature=temperature, use_inference_z=use_inference_z)
+            soft, idx = self._approx_with_index(glp, args.gen_approx_mode)
+            if not args.use_learnable:
+                glen = self.get_lengths(idx, eos_idx)
+            return soft, glen
+
+        if overlap:
+            with torch.cuda.stream(side):
+                gen_soft_tokens, gen_lengths = transfer_pass()
+            main.wait_stream(side)
+            gen_soft_tokens.record_stream(main)
+            gen_lengths.record_stream(main)
+        else:
+            gen_soft_tokens, gen_lengths = transfer_pass()
 
         cyc_nll, _, cyc_length_losses, cyc_gen_error, _ = model_F(
             gen_soft_tokens, gen_lengths, inp_tokens, inp_lengths, raw_styles,
