@@ -227,9 +227,13 @@ def main():
         # the steps (they contain the gradient all-reduce); rank 0 reports its own kernels.
         from nast_amd import _lib
         lib = _lib.load()
+        # The two-stream overlap is switched off for this pass: an event pair around a launch measures that
+        # kernel's own duration only while nothing else shares the GPU with it.
+        model.overlap_passes = False
         lib.nast_prof_begin(0)        # every family: 1 GEMM, 2 vocabulary row kernels, 3 alignment DP
         run(min(a.steps, 5), offset=a.warmup)
         torch.cuda.synchronize()
+        model.overlap_passes = not a.no_overlap
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         lib.nast_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
         if rank == 0 and ms.value > 0:

@@ -56,6 +56,7 @@ class GradReducer:
         self.plan = None
         self.tag = None
         self._fired = []
+        self._streams = ()
         if self.enabled:
             from . import ops
             for i, p in enumerate(self.params):
@@ -92,12 +93,14 @@ class GradReducer:
             if self._ready[b] == len(plan.buckets[b]):
                 self._launch(b)
 
-    def arm(self, tag="default"):
-        """Call right before the backward pass whose gradients are final for this step."""
+    def arm(self, tag="default", streams=()):
+        """Call right before the backward pass whose gradients are final for this step.  `streams`: every HIP
+        stream that backward's kernels run on, when more than one (a bucket waits for all of them before it leaves)."""
         if not self.enabled:
             return
         self.armed = True
         self.tag = tag
+        self._streams = tuple(streams)
         self.plan = self.plans.get(tag)
         self._fired = []
         self._dirty = False
@@ -139,6 +142,11 @@ class GradReducer:
 
     def _launch(self, b):
         plan = self.plan
+        # the last contribution may come from a node on one stream while earlier ones are still queued on another
+        cur = torch.cuda.current_stream() if self._streams else None
+        for st in self._streams:
+            if st != cur:
+                cur.wait_stream(st)
         grads = [self.params[i].grad for i in plan.buckets[b]]
         views = self._views(plan, b)
         for v, g in zip(views, grads):

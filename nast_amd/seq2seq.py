@@ -261,11 +261,17 @@ class Seq2seq(BaseModel):
         adv_factor = (raw_styles == 0) * args.fw_adv_factor + (raw_styles == 1) * args.bw_adv_factor
         adv_loss = (adv_loss * adv_factor).sum() / batch_size
 
-        self.reducer_F.arm("f_full")
+        self.reducer_F.arm("f_full", streams=(main, side) if overlap else ())
         if args.use_learnable:
             (cyc_rec_loss + adv_loss + cyc_rec_length_loss).backward()
         else:
             (cyc_rec_loss + adv_loss).backward()
+        if overlap:
+            # autograd ran the transfer pass's backward nodes on the side stream (the stream of their forward) and
+            # joins only the streams of AccumulateGrad nodes at the end of backward; the kernels here accumulate
+            # into .grad in place, so no such node exists on the side stream: join it explicitly before the
+            # gradients are read (clip, Adam, all-reduce write-back) and before any buffer it reads is recycled.
+            main.wait_stream(side)
         self.reducer_F.finish()
 
         self.last_grad_norm = clip_grad_norm_(self.net.model_F.parameters(), 5)
