@@ -30,7 +30,8 @@ void nast_set_error(const char* fmt, ...);
 
 // ---- in-library profiling hooks (prof.hip) -------------------------------------------------
 void nast_prof_before(int kind, hipStream_t s);
-void nast_prof_after(int kind, hipStream_t s, double flops);
+void nast_prof_after(int kind, hipStream_t s, double work, const char* sig = nullptr);
+bool nast_prof_shapes(int kind);   // true when per-signature timing is wanted (NAST_PROF_SHAPES set and the family armed)
 
 // ---- wave / block reductions (64-wide wavefronts) ------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1,5 +1,8 @@
 // Error string, version and the in-library event profiler used by bench.py's roofline block.
+#include <algorithm>
+#include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -21,6 +24,8 @@ namespace {
 constexpr int NKIND = 4;       // 1 = GEMM (work = FLOP), 2 = vocabulary row kernels (work = algorithmic bytes), 3 = alignment DP (bytes)
 struct Fam {
   std::vector<hipEvent_t> ev;   // pairs
+  std::vector<std::string> sig; // per pair: problem signature (only kept when NAST_PROF_SHAPES is set)
+  std::vector<double> wk;
   double work = 0;
   int64_t launches = 0;
   double ms = 0;
@@ -51,13 +56,23 @@ void nast_prof_before(int kind, hipStream_t s) {
   g_prof.fam[kind].ev.push_back(e);
 }
 
-void nast_prof_after(int kind, hipStream_t s, double work) {
+bool nast_prof_shapes(int kind) {
+  static const bool on = getenv("NAST_PROF_SHAPES") != nullptr;
+  return on && armed(kind);
+}
+
+void nast_prof_after(int kind, hipStream_t s, double work, const char* sig) {
   if (!armed(kind)) return;
   hipEvent_t e = get_event();
   hipEventRecord(e, s);
-  g_prof.fam[kind].ev.push_back(e);
-  g_prof.fam[kind].work += work;
-  g_prof.fam[kind].launches += 1;
+  Fam& f = g_prof.fam[kind];
+  f.ev.push_back(e);
+  f.work += work;
+  f.launches += 1;
+  if (nast_prof_shapes(kind)) {
+    f.sig.emplace_back(sig ? sig : "");
+    f.wk.push_back(work);
+  }
 }
 
 extern "C" int nast_prof_begin(int kind) {
@@ -66,6 +81,7 @@ extern "C" int nast_prof_begin(int kind) {
     Fam& f = g_prof.fam[k];
     for (hipEvent_t e : f.ev) g_prof.pool.push_back(e);
     f.ev.clear();
+    f.sig.clear(); f.wk.clear();
     f.work = 0; f.launches = 0; f.ms = 0;
   }
   return NAST_OK;
@@ -75,10 +91,24 @@ static void prof_collect() {
   g_prof.mask = 0;
   for (int k = 0; k < NKIND; ++k) {
     Fam& f = g_prof.fam[k];
+    struct Agg { double ms = 0, work = 0; int n = 0; };
+    std::map<std::string, Agg> by_sig;
     for (size_t i = 0; i + 1 < f.ev.size(); i += 2) {
       hipEventSynchronize(f.ev[i + 1]);
       float t = 0;
       if (hipEventElapsedTime(&t, f.ev[i], f.ev[i + 1]) == hipSuccess) f.ms += t;
+      if (i / 2 < f.sig.size()) {
+        Agg& a = by_sig[f.sig[i / 2]];
+        a.ms += t; a.work += f.wk[i / 2]; a.n += 1;
+      }
+    }
+    if (!by_sig.empty()) {   // tuning aid (NAST_PROF_SHAPES=1): time per problem signature, largest first
+      std::vector<std::pair<std::string, Agg>> v(by_sig.begin(), by_sig.end());
+      std::sort(v.begin(), v.end(), [](auto& x, auto& y) { return x.second.ms > y.second.ms; });
+      fprintf(stderr, "[nast_prof] family %d: %.3f ms over %lld launches\n", k, f.ms, (long long)f.launches);
+      for (auto& e : v)
+        fprintf(stderr, "[nast_prof]  %8.3f ms  n=%5d  avg %8.2f us  %7.2f Twork/s  %s\n", e.second.ms, e.second.n,
+                e.second.ms * 1e3 / e.second.n, e.second.work / (e.second.ms * 1e-3) / 1e12, e.first.c_str());
     }
     for (hipEvent_t e : f.ev) g_prof.pool.push_back(e);
     f.ev.clear();

@@ -15,6 +15,8 @@
 //   B: transB=1 -> k-contiguous [N][K]   | transB=0 -> n-contiguous [K][N]   (dgrad: W, wgrad: X)
 #include <stdlib.h>
 
+#include <string>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -724,7 +726,19 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
     if (cfg == 2) plan_and_launch<128, 128, NAST_BK128>(descs, count, stream, false, nullptr);
     else plan_and_launch<64, 64, 32>(descs, count, stream, false, nullptr);
   }
-  nast_prof_after(1, stream, flops);
+  if (nast_prof_shapes(1)) {
+    std::string sig = skinny ? "skinny" : (tilesL >= 4096 ? "t128" : "t64");
+    for (int i = 0; i < count; ++i) {
+      const nast_gemm_desc& d = descs[i];
+      char b[160];
+      snprintf(b, sizeof(b), " [%dx%dx%d ta%d tb%d x%d f%d%s%s%s%s]", d.M, d.N, d.K, d.transA, d.transB, d.nsrc, d.flags,
+               d.bias ? " b" : "", d.residual ? " r" : "", d.colsum ? " cs" : "", d.ln_gamma ? " ln" : "");
+      sig += b;
+    }
+    nast_prof_after(1, stream, flops, sig.c_str());
+  } else {
+    nast_prof_after(1, stream, flops);
+  }
   NAST_CHECK_LAUNCH("nast_gemm_f32");
   return NAST_OK;
 }
