@@ -18,6 +18,8 @@
 // instead of transposing the score tiles: 7 small products per (sentence, head), all on MFMA.
 //
 // Limits: nq, nk <= 64 and dk in {8, 16, 32, 64}; longer sequences use the LDS kernels in attention.hip.
+#include <type_traits>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -191,14 +193,37 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_mfma_kernel(const AttnArgs P
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Backward.  Two exact short cuts cut the padded work of a batch of ragged sentences to about a third:
+//   * key tiles that are masked for every query (a key-padding mask, mask_qs == 0, hides the tail of the
+//     sentence) have P == 0: they are not staged, not multiplied, and their dK / dV rows are written as zeros;
+//   * query tiles whose dO rows are all zero (padded target positions carry no loss) have dP == delta == dS == 0:
+//     they add nothing to dK / dV and their dQ rows are zeros.  The test is made on the data while dO is staged.
+// ---------------------------------------------------------------------------------------------------------
+template <int DK>
+__device__ __forceinline__ void stage_rows_flag(float* __restrict__ dst, const float* __restrict__ src, int64_t ld, int rows, int rows_pad,
+                                                int* __restrict__ tile_flag) {
+  constexpr int LD = DK + 4, V4 = DK / 4;
+  for (int c = threadIdx.x; c < rows_pad * V4; c += 256) {
+    const int r = c / V4, q = (c % V4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) v = *reinterpret_cast<const float4*>(src + (int64_t)r * ld + q);
+    *reinterpret_cast<float4*>(dst + r * LD + q) = v;
+    if (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f) tile_flag[r >> 4] = 1;   // benign race: every writer stores 1
+  }
+}
+
 template <int DK, int NT>
-__global__ __launch_bounds__(256) void nast_mha_bwd_mfma_kernel(const AttnArgs P) {
+__global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel(const AttnArgs P) {
   constexpr int NS = DK / 4, NCT = (DK + 15) / 16, LD = DK + 4;
   __shared__ __attribute__((aligned(16))) float Ks[NT * 16 * LD];
   __shared__ __attribute__((aligned(16))) float Vs[NT * 16 * LD];
   __shared__ __attribute__((aligned(16))) float Qs[NT * 16 * LD];
   __shared__ __attribute__((aligned(16))) float Gs[NT * 16 * LD];
-  __shared__ float dlt[NT * 16];                // delta[i] = sum_j P[i][j] dP[i][j]
+  __shared__ __attribute__((aligned(16))) float dlt[NT * 16];     // delta[i] = sum_j P[i][j] dP[i][j]
+  __shared__ __attribute__((aligned(16))) float lse_s[NT * 16];
+  __shared__ unsigned long long dead_q[NT * 16];   // per query: bit j set = key j gets no attention weight
+  __shared__ unsigned long long dead_k[NT * 16];   // per key: bit i set = query i gives it no weight
+  __shared__ int live_q[NT];                    // query tile has a non-zero dO row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r15 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.x;
   const int b = bh / P.h, head = bh % P.h;
@@ -206,89 +231,174 @@ __global__ __launch_bounds__(256) void nast_mha_bwd_mfma_kernel(const AttnArgs P
   float* dQb = P.dq + b * P.q_bs + head * DK;
   float* dKb = P.dk + b * P.k_bs + head * DK;
   float* dVb = P.dv + b * P.v_bs + head * DK;
-  const float* lse = P.lse_in + (int64_t)bh * nq;
   const float scale = P.scale;
   const int nqt = (nq + 15) / 16, nkt = (nk + 15) / 16;
-  stage_rows<DK>(Ks, P.k + b * P.k_bs + head * DK, P.ldk, nk, NT * 16);
-  stage_rows<DK>(Vs, P.v + b * P.v_bs + head * DK, P.ldv, nk, NT * 16);
-  stage_rows<DK>(Qs, P.q + b * P.q_bs + head * DK, P.ldq, nq, NT * 16);
-  stage_rows<DK>(Gs, P.dout + b * P.o_bs + head * DK, P.ldo, nq, NT * 16);
+  // Everything the two phases read comes to LDS in ONE global round trip: K, V, Q, dO rows, the log-sum-exp row and
+  // the mask as dead flags in both orientations.  Keys past the last unmasked one (same for every query when
+  // mask_qs == 0) never take part.
+  const bool pad_mask = P.mask != nullptr && P.mask_qs == 0;
+  if (threadIdx.x < NT) live_q[threadIdx.x] = 0;
   __syncthreads();
+  // mask bytes: NT*4 rows of each orientation per wavefront (lane = key for dead_q, lane = query for dead_k)
+  uint8_t mq_b[NT * 4], mk_b[NT * 4];
+#pragma unroll
+  for (int u = 0; u < NT * 4; ++u) {
+    const int row = 4 * u + wave;
+    const int ic = row < nq ? row : nq - 1, jl = lane < nk ? lane : nk - 1;
+    const int jc = row < nk ? row : nk - 1, il = lane < nq ? lane : nq - 1;
+    mq_b[u] = P.mask != nullptr ? P.mask[b * P.mask_bs + (int64_t)ic * P.mask_qs + jl] : (uint8_t)0;
+    mk_b[u] = P.mask != nullptr ? P.mask[b * P.mask_bs + (int64_t)il * P.mask_qs + jc] : (uint8_t)0;
+  }
+  {
+    // all global loads of the four operand images are issued before the first LDS store (one memory round trip)
+    constexpr int V4 = DK / 4, CH = (NT * 16 * V4 + 255) / 256;
+    float4 rk[CH], rv[CH], rq[CH], rg[CH];
+    const float* Kg = P.k + b * P.k_bs + head * DK;
+    const float* Vg = P.v + b * P.v_bs + head * DK;
+    const float* Qg = P.q + b * P.q_bs + head * DK;
+    const float* Gg = P.dout + b * P.o_bs + head * DK;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int c = threadIdx.x + 256 * u, r = c / V4, q = (c % V4) * 4;
+      rk[u] = rv[u] = rq[u] = rg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nk) {
+        rk[u] = *reinterpret_cast<const float4*>(Kg + (int64_t)r * P.ldk + q);
+        rv[u] = *reinterpret_cast<const float4*>(Vg + (int64_t)r * P.ldv + q);
+      }
+      if (r < nq) {
+        rq[u] = *reinterpret_cast<const float4*>(Qg + (int64_t)r * P.ldq + q);
+        rg[u] = *reinterpret_cast<const float4*>(Gg + (int64_t)r * P.ldo + q);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int c = threadIdx.x + 256 * u, r = c / V4, q = (c % V4) * 4;
+      if (r < NT * 16) {
+        *reinterpret_cast<float4*>(Ks + r * LD + q) = rk[u];
+        *reinterpret_cast<float4*>(Vs + r * LD + q) = rv[u];
+        *reinterpret_cast<float4*>(Qs + r * LD + q) = rq[u];
+        *reinterpret_cast<float4*>(Gs + r * LD + q) = rg[u];
+        if (rg[u].x != 0.f || rg[u].y != 0.f || rg[u].z != 0.f || rg[u].w != 0.f) live_q[r >> 4] = 1;   // benign race: all store 1
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < nqt * 16; i += 256) lse_s[i] = P.lse_in[(int64_t)bh * nq + (i < nq ? i : nq - 1)];
+  // dead-flag bit rows by wave ballots (the bytes were requested before the operand images)
+#pragma unroll
+  for (int u = 0; u < NT * 4; ++u) {
+    const int row = 4 * u + wave;
+    const unsigned long long mq = __ballot(row >= nq || lane >= nk || mq_b[u] != 0);
+    const unsigned long long mk = __ballot(row >= nk || lane >= nq || mk_b[u] != 0);
+    if (lane == 0) {
+      dead_q[row] = mq;
+      dead_k[row] = mk;
+    }
+  }
+  __syncthreads();
+  // keys past the last one that any query may see never take part (a key-padding mask hides the sentence tail)
+  int nk_e = nk;
+  if (pad_mask) {
+    const unsigned long long seen = ~dead_q[0];
+    if (seen != 0ull) nk_e = 64 - __clzll((long long)seen);   // all keys masked: keep the plain path (NaN like the reference)
+  }
+  const int nkt_e = (nk_e + 15) / 16;
 
   // ---- phase 1: lane = query.  dQ[i][c] = scale * sum_j dS[i][j] K[j][c] -----------------------------------
   for (int it = wave; it < nqt; it += 4) {
-    const int i = 16 * it + r15;
-    const int ic = i < nq ? i : nq - 1;
-    float qf[NS], gf[NS];
-    lds_frag<DK>(qf, Qs + (16 * it + r15) * LD, g);
-    lds_frag<DK>(gf, Gs + (16 * it + r15) * LD, g);
-    const float l = lse[ic];
-    const uint8_t* mrow = P.mask ? P.mask + b * P.mask_bs + (int64_t)ic * P.mask_qs : nullptr;
-    f32x4 st[NT], dp[NT];
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt) {
-      float kf[NS], vf[NS];
-      lds_frag<DK>(kf, Ks + (16 * jt + r15) * LD, g);
-      lds_frag<DK>(vf, Vs + (16 * jt + r15) * LD, g);
-      st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        st[jt] = mfma4(kf[s], qf[s], st[jt]);
-        dp[jt] = mfma4(vf[s], gf[s], dp[jt]);
+    if (!live_q[it]) {                           // dO == 0 for the whole tile: dQ rows are zero
+      for (int c = lane; c < 16 * (DK / 4); c += 64) {
+        const int io = 16 * it + c / (DK / 4), q4 = (c % (DK / 4)) * 4;
+        if (io < nq) *reinterpret_cast<float4*>(dQb + (int64_t)io * P.ldq + q4) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
+      continue;
     }
-    float dsum = 0.f;
+    // the tile's work for NKE live key tiles; NKE is a compile-time constant so that every loop unrolls and the
+    // score registers stay registers
+    auto q_tile = [&](auto nke_c) {
+      constexpr int NKE = decltype(nke_c)::value;
+      float qf[NS], gf[NS];
+      lds_frag<DK>(qf, Qs + (16 * it + r15) * LD, g);
+      lds_frag<DK>(gf, Gs + (16 * it + r15) * LD, g);
+      const float l = lse_s[16 * it + r15];
+      f32x4 st[NKE], dp[NKE];
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
+      for (int jt = 0; jt < NKE; ++jt) {
+        float kf[NS], vf[NS];
+        lds_frag<DK>(kf, Ks + (16 * jt + r15) * LD, g);
+        lds_frag<DK>(vf, Vs + (16 * jt + r15) * LD, g);
+        st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * jt + 4 * g + r;
-        const bool dead = j >= nk || i >= nq || (mrow && mrow[j < nk ? j : 0]);
-        const float p = dead ? 0.f : __expf(st[jt][r] * scale - l);
-        st[jt][r] = p;
-        dsum = fmaf(p, dp[jt][r], dsum);
-      }
-    dsum = xor_sum_g(dsum);
-    if (g == 0) dlt[16 * it + r15] = dsum;
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) st[jt][r] = st[jt][r] * (dp[jt][r] - dsum) * scale;   // dS * scale
-    f32x4 acc[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* kr = Ks + (16 * jt + 4 * g + r) * LD;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const int c = 16 * ct + r15;
-          const float bv = (DK >= 16 || c < DK) ? kr[c < DK ? c : 0] : 0.f;
-          acc[ct] = mfma4(st[jt][r], bv, acc[ct]);
+        for (int s = 0; s < NS; ++s) {
+          st[jt] = mfma4(kf[s], qf[s], st[jt]);
+          dp[jt] = mfma4(vf[s], gf[s], dp[jt]);
         }
       }
+      float dsum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int io = 16 * it + 4 * g + r;
-      if (io < nq) {
+      for (int jt = 0; jt < NKE; ++jt) {
+        const uint32_t dw = (uint32_t)(dead_q[16 * it + r15] >> (16 * jt + 4 * g)) & 15u;
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const int c = 16 * ct + r15;
-          if (DK >= 16 || c < DK) dQb[(int64_t)io * P.ldq + c] = acc[ct][r];
+        for (int r = 0; r < 4; ++r) {
+          const bool dead = (dw >> r) & 1u;
+          const float p = dead ? 0.f : __expf(st[jt][r] * scale - l);
+          st[jt][r] = p;
+          dsum = fmaf(p, dp[jt][r], dsum);
         }
       }
-    }
+      dsum = xor_sum_g(dsum);
+      if (g == 0) dlt[16 * it + r15] = dsum;
+#pragma unroll
+      for (int jt = 0; jt < NKE; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[jt][r] = st[jt][r] * (dp[jt][r] - dsum) * scale;   // dS * scale
+      f32x4 acc[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jt = 0; jt < NKE; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* kr = Ks + (16 * jt + 4 * g + r) * LD;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const int c = 16 * ct + r15;
+            const float bv = (DK >= 16 || c < DK) ? kr[c < DK ? c : 0] : 0.f;
+            acc[ct] = mfma4(st[jt][r], bv, acc[ct]);
+          }
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int io = 16 * it + 4 * g + r;
+        if (io < nq) {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const int c = 16 * ct + r15;
+            if (DK >= 16 || c < DK) dQb[(int64_t)io * P.ldq + c] = acc[ct][r];
+          }
+        }
+      }
+    };
+    if (NT >= 4 && nkt_e >= 4) q_tile(std::integral_constant<int, NT >= 4 ? 4 : 1>{});
+    else if (NT >= 3 && nkt_e == 3) q_tile(std::integral_constant<int, NT >= 3 ? 3 : 1>{});
+    else if (NT >= 2 && nkt_e == 2) q_tile(std::integral_constant<int, NT >= 2 ? 2 : 1>{});
+    else q_tile(std::integral_constant<int, 1>{});
   }
   __syncthreads();   // dlt is read by other wavefronts below
 
   // ---- phase 2: lane = key.  dK[j][c] = scale * sum_i dS[i][j] Q[i][c],  dV[j][c] = sum_i P[i][j] dO[i][c] ----
   for (int jt = wave; jt < nkt; jt += 4) {
-    const int j = 16 * jt + r15;                 // this lane's key
-    const int jc = j < nk ? j : nk - 1;
-    float kf[NS], vf[NS];
+    if (jt >= nkt_e) {                            // every key of the tile is masked: dK = dV = 0
+      for (int c = lane; c < 16 * (DK / 4); c += 64) {
+        const int jo = 16 * jt + c / (DK / 4), q4 = (c % (DK / 4)) * 4;
+        if (jo < nk) {
+          *reinterpret_cast<float4*>(dKb + (int64_t)jo * P.ldk + q4) = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(dVb + (int64_t)jo * P.ldv + q4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      continue;
+    }
+    float kf[NS], vf[NS];                        // this lane's key: j = 16 jt + r15
     lds_frag<DK>(kf, Ks + (16 * jt + r15) * LD, g);
     lds_frag<DK>(vf, Vs + (16 * jt + r15) * LD, g);
     f32x4 accK[NCT], accV[NCT];
@@ -299,7 +409,7 @@ __global__ __launch_bounds__(256) void nast_mha_bwd_mfma_kernel(const AttnArgs P
     }
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
-      if (it < nqt) {
+      if (it < nqt && live_q[it]) {
         // S[i][j] and dP[i][j] with row = query 16 it + 4 g + r, col = key j
         float qf[NS], gf[NS];
         lds_frag<DK>(qf, Qs + (16 * it + r15) * LD, g);
@@ -311,14 +421,16 @@ __global__ __launch_bounds__(256) void nast_mha_bwd_mfma_kernel(const AttnArgs P
           d4 = mfma4(gf[s], vf[s], d4);
         }
         f32x4 p4, ds4;
+        const uint32_t dw = (uint32_t)(dead_k[16 * jt + r15] >> (16 * it + 4 * g)) & 15u;
+        const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[16 * it + 4 * g]);
+        const float4 t4 = *reinterpret_cast<const float4*>(&dlt[16 * it + 4 * g]);
+        const f32x4 lr = {l4.x, l4.y, l4.z, l4.w}, tr = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int i = 16 * it + 4 * g + r;
-          const int ic = i < nq ? i : nq - 1;
-          const bool dead = i >= nq || j >= nk || (P.mask && P.mask[b * P.mask_bs + (int64_t)ic * P.mask_qs + jc]);
-          const float p = dead ? 0.f : __expf(s4[r] * scale - lse[ic]);
+          const bool dead = (dw >> r) & 1u;
+          const float p = dead ? 0.f : __expf(s4[r] * scale - lr[r]);
           p4[r] = p;
-          ds4[r] = p * (d4[r] - dlt[16 * it + 4 * g + r]) * scale;
+          ds4[r] = p * (d4[r] - tr[r]) * scale;
         }
         // A = dS / P registers (row = key lane, k = query 16 it + 4 g + r), B = Q / dO [query][channel]
 #pragma unroll

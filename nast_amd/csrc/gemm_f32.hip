@@ -659,6 +659,33 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
     }
     per_of[i] = per; sk_of[i] = sk; order[i] = i;
   }
+  // Round quantisation: all workgroup slots of the chip (SLOTS = resident workgroups per CU x 256) fill at once, so a
+  // launch of q*SLOTS + r workgroups with a small r pays a whole extra round for the r stragglers (measured: 1056
+  // against 1024 tiles costs +18 %).  When the group has atomically accumulated members, their slice count is
+  // lowered (slices get a little longer) until the total drops to q*SLOTS.
+  {
+    constexpr int SLOTS = (BM >= 128) ? 512 : 1024;
+    static const bool fit = [] { const char* e = getenv("NAST_GEMM_FIT"); return e ? atoi(e) != 0 : true; }();   // tuning aid
+    int W = 0;
+    for (int i = 0; i < count; ++i) W += P.tiles_m[i] * P.tiles_n[i] * sk_of[i];
+    int r = W % SLOTS;
+    if (fit && W > SLOTS && r > 0 && r <= SLOTS / 4) {
+      for (int i = 0; i < count && r > 0; ++i) {
+        if (!(descs[i].flags & NAST_GEMM_ATOMIC) || sk_of[i] < 2) continue;
+        const int t = P.tiles_m[i] * P.tiles_n[i];
+        if (t <= 0) continue;
+        const int nkt = (descs[i].K + BK - 1) / BK;
+        int drop = (r + t - 1) / t;
+        if (drop > sk_of[i] / 4) drop = sk_of[i] / 4;          // never lengthen a slice by more than a third
+        if (drop <= 0) continue;
+        int sk = sk_of[i] - drop;
+        const int per = (nkt + sk - 1) / sk;
+        sk = (nkt + per - 1) / per;
+        r -= (sk_of[i] - sk) * t;
+        per_of[i] = per; sk_of[i] = sk;
+      }
+    }
+  }
   for (int a = 1; a < count; ++a)     // insertion sort by per-workgroup work, descending
     for (int b = a; b > 0 && per_of[order[b]] * descs[order[b]].nsrc > per_of[order[b - 1]] * descs[order[b - 1]].nsrc; --b) {
       const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t;

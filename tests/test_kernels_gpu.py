@@ -144,6 +144,34 @@ def test_attention(ops, B, nq, nk, h, dk, kind):
     relclose(y, yref); relclose(qg.grad, qr.grad); relclose(kg.grad, kr.grad); relclose(vg.grad, vr.grad)
 
 
+@pytest.mark.parametrize("B,n,h,dk,holes", [(6, 33, 4, 64, False), (5, 48, 2, 32, False), (4, 33, 4, 64, True), (3, 20, 4, 16, True)])
+def test_attention_ragged_backward(ops, B, n, h, dk, holes):
+    """The backward kernel skips key tiles masked for every query and query tiles whose cotangent rows are all zero
+    (what a ragged batch looks like: padded positions carry no loss).  Both short cuts must be exact, also for a key
+    mask with holes (unmasked keys after masked ones) and for lengths that end inside a 16-row tile."""
+    g = torch.Generator().manual_seed(7 * B + n)
+    D = h * dk
+    q, k, v = (torch.randn(B, n, D, generator=g) for _ in range(3))
+    lens = torch.randint(1, n + 1, (B,), generator=g)
+    lens[0], lens[-1] = n, 1
+    mask = (torch.arange(n)[None] >= lens[:, None])
+    if holes:
+        mask = mask | (torch.rand(B, n, generator=g) < 0.3)
+        mask[:, 0] = False
+    mask = mask.view(B, 1, 1, n)
+    R = torch.randn(B, n, D, generator=g)
+    R = R * (torch.arange(n)[None] < lens[:, None]).unsqueeze(-1)        # zero cotangent at padded queries
+    if holes:
+        R[1, 3:9] = 0                                                    # zero rows inside a live tile
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    yref = ref_attention(qr, kr, vr, mask, h)
+    (yref * R).sum().backward()
+    qg, kg, vg = (dev(t).requires_grad_(True) for t in (q, k, v))
+    y = ops.attention(qg, kg, vg, dev(mask), h)
+    (y * dev(R)).sum().backward()
+    relclose(y, yref); relclose(qg.grad, qr.grad); relclose(kg.grad, kr.grad); relclose(vg.grad, vr.grad)
+
+
 @pytest.mark.parametrize("rows,V", [(6, 40), (33, 9600), (5, 1001), (3, 32000)])
 def test_log_softmax_and_generator(ops, rows, V):
     g = torch.Generator().manual_seed(V)

@@ -87,7 +87,12 @@ static void run(const char* name, std::vector<nast_gemm_desc> g, int iters = 20)
 int main(int argc, char** argv) {
   const int d = 256, ff = 1024, V = 9600;
   if (argc > 1) g_filter = argv[1];   // substring filter on the case name
-  for (int M : {2112, 16896}) {
+  std::vector<int> Ms_list = {2112, 16896};
+  if (getenv("GB_M")) {   // GB_M=16384,16896: other row counts (tile-quantisation experiments)
+    Ms_list.clear();
+    for (char* t = strtok(strdup(getenv("GB_M")), ","); t; t = strtok(nullptr, ",")) Ms_list.push_back(atoi(t));
+  }
+  for (int M : Ms_list) {
     const int Mv = M == 2112 ? 2048 : 16384;
     const int rotn = getenv("GB_ROT") ? atoi(getenv("GB_ROT")) : 1;
     float* x = dalloc((size_t)M * ff * rotn);
