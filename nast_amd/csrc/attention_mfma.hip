@@ -468,8 +468,12 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
 
 // ---------------------------------------------------------------------------------------------------------
 // Forward, one WAVEFRONT per (sentence, head), operands straight from global memory (no LDS, no barrier): measured
-// faster than the workgroup-cooperative LDS variant above for the forward pass (15.7 vs 21.7 us at 2048 heads of
-// 33 x 33 x 64), because a forward tile has too little arithmetic to amortise the staging round trip.
+// faster than the workgroup-cooperative LDS variant above for the forward pass, because a forward tile has too
+// little arithmetic to amortise the staging round trip.  The kernel is latency-bound, so it is organised around
+// memory round trips: K row fragments AND the V column operands of every live key tile are fetched once, before
+// the query loop (they do not depend on the query tile), and the next query tile's Q fragment (and mask bits) is
+// requested before the current tile's arithmetic.  Key tiles that a key-padding mask (mask_qs == 0) hides for every
+// query contribute exp(-inf) = 0 exactly and are skipped: the body is specialised on the number of live key tiles.
 // ---------------------------------------------------------------------------------------------------------
 template <int DK, int NKT>
 __global__ __launch_bounds__(256) void nast_mha_fwd_wave_kernel(const AttnArgs P) {
@@ -483,59 +487,53 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_wave_kernel(const AttnArgs P
   const float* Vb = P.v + b * P.v_bs + head * DK;
   const float* Qb = P.q + b * P.q_bs + head * DK;
   float* Ob = P.out + b * P.o_bs + head * DK;
-  // K rows of all key tiles stay in registers
-  float kf[NKT][NS];
-#pragma unroll
-  for (int jt = 0; jt < NKT; ++jt) {
-    int j = 16 * jt + r15;
-    j = j < nk ? j : nk - 1;
-    load_frag<DK>(kf[jt], Kb + (int64_t)j * P.ldk, g);
-  }
   const int nqt = (nq + 15) / 16;
-  for (int it = 0; it < nqt; ++it) {
-    const int i = 16 * it + r15;                 // this lane's query
-    const int ic = i < nq ? i : nq - 1;
-    float qf[NS];
-    load_frag<DK>(qf, Qb + (int64_t)ic * P.ldq, g);
-    f32x4 st[NKT];
+  const bool pad_mask = P.mask != nullptr && P.mask_qs == 0;
+  const bool row_mask = P.mask != nullptr && P.mask_qs != 0;
+  // bit j set = key j takes no weight (for every query when the mask is a key-padding mask)
+  unsigned long long dead_row = nk < 64 ? (~0ull << nk) : 0ull;
+  int nk_e = nk;
+  if (pad_mask) {
+    dead_row |= __ballot(lane < nk && P.mask[b * P.mask_bs + (lane < nk ? lane : 0)] != 0);
+    const unsigned long long seen = ~dead_row;
+    if (seen != 0ull) nk_e = 64 - __clzll((long long)seen);   // all keys masked: plain path (NaN like the reference)
+  }
+  const int nkt_e = (nk_e + 15) / 16;
+
+  auto run = [&](auto nke_c) {
+    constexpr int NKE = decltype(nke_c)::value;
+    // 4 dead bits (r = 0..3) per key tile for this lane's query of tile `it`
+    auto dead_bits = [&](int it) -> uint32_t {
+      uint32_t w = 0;
+      if (row_mask) {
+        const int i = 16 * it + r15;
+        const uint8_t* mrow = P.mask + b * P.mask_bs + (int64_t)(i < nq ? i : nq - 1) * P.mask_qs;
 #pragma unroll
-    for (int jt = 0; jt < NKT; ++jt) {
-      st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jt = 0; jt < NKE; ++jt)
 #pragma unroll
-      for (int s = 0; s < NS; ++s) st[jt] = mfma4(kf[jt][s], qf[s], st[jt]);
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + 4 * g + r;
+            w |= (uint32_t)(j >= nk || mrow[j < nk ? j : 0] != 0) << (4 * jt + r);
+          }
+      } else {
+#pragma unroll
+        for (int jt = 0; jt < NKE; ++jt) w |= ((uint32_t)(dead_row >> (16 * jt + 4 * g)) & 15u) << (4 * jt);
+      }
+      return w;
+    };
+    float kf[NKE][NS];
+    float vc[NKE][4][NCT];
+#pragma unroll
+    for (int jt = 0; jt < NKE; ++jt) {
+      int j = 16 * jt + r15;
+      j = j < nk ? j : nk - 1;
+      load_frag<DK>(kf[jt], Kb + (int64_t)j * P.ldk, g);
     }
-    // softmax over keys j = 16 jt + 4 g + r for query i
-    const uint8_t* mrow = P.mask ? P.mask + b * P.mask_bs + (int64_t)ic * P.mask_qs : nullptr;
-    float mx = -INFINITY;
+    float qf[NS];
+    load_frag<DK>(qf, Qb + (int64_t)(r15 < nq ? r15 : nq - 1) * P.ldq, g);
+    uint32_t dbits = dead_bits(0);
 #pragma unroll
-    for (int jt = 0; jt < NKT; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * jt + 4 * g + r;
-        float s = st[jt][r] * P.scale;
-        if (j >= nk || (mrow && mrow[j < nk ? j : 0])) s = -INFINITY;
-        st[jt][r] = s;
-        mx = fmaxf(mx, s);
-      }
-    mx = xor_max_g(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int jt = 0; jt < NKT; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(st[jt][r] - mx);
-        st[jt][r] = e;
-        sum += e;
-      }
-    sum = xor_sum_g(sum);
-    const float inv = 1.f / sum;
-    if (g == 0 && i < nq) P.lse[(int64_t)bh * nq + i] = mx + __logf(sum);
-    // O[i][c] = sum_j P[i][j] V[j][c]: A = the score registers, B = V[j = 16 jt + 4 g + r][16 ct + lane&15]
-    f32x4 o[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int jt = 0; jt < NKT; ++jt)
+    for (int jt = 0; jt < NKE; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int j = 16 * jt + 4 * g + r;
@@ -544,24 +542,84 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_wave_kernel(const AttnArgs P
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
           const int c = 16 * ct + r15;
-          const float bv = (DK >= 16 || c < DK) ? vr[c < DK ? c : 0] : 0.f;
-          o[ct] = mfma4(st[jt][r], bv, o[ct]);
+          vc[jt][r][ct] = (DK >= 16 || c < DK) ? vr[c < DK ? c : 0] : 0.f;
         }
       }
-    // the result tile: col = channel 16 ct + lane&15, row = query 16 it + 4 g + r; 1/sum belongs to the ROW's query
+    for (int it = 0; it < nqt; ++it) {
+      const int i = 16 * it + r15;                 // this lane's query
+      float qn[NS];
+      uint32_t dnext = 0;
+      const bool more = it + 1 < nqt;
+      if (more) {                                  // next tile's operands travel while this tile computes
+        const int in = i + 16;
+        load_frag<DK>(qn, Qb + (int64_t)(in < nq ? in : nq - 1) * P.ldq, g);
+        dnext = dead_bits(it + 1);
+      }
+      f32x4 st[NKE];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int io = 16 * it + 4 * g + r;
-      const float invr = __shfl(inv, 4 * g + r, 64);   // lane (4 g + r) of group 0 holds query 16 it + 4 g + r
-      if (io < nq) {
+      for (int jt = 0; jt < NKE; ++jt) {
+        st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const int c = 16 * ct + r15;
-          if (DK >= 16 || c < DK) Ob[(int64_t)io * P.ldo + c] = o[ct][r] * invr;
+        for (int s = 0; s < NS; ++s) st[jt] = mfma4(kf[jt][s], qf[s], st[jt]);
+      }
+      // softmax over keys j = 16 jt + 4 g + r for query i
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < NKE; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sc = st[jt][r] * P.scale;
+          if ((dbits >> (4 * jt + r)) & 1u) sc = -INFINITY;
+          st[jt][r] = sc;
+          mx = fmaxf(mx, sc);
         }
+      mx = xor_max_g(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < NKE; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(st[jt][r] - mx);
+          st[jt][r] = e;
+          sum += e;
+        }
+      sum = xor_sum_g(sum);
+      const float inv = 1.f / sum;
+      if (g == 0 && i < nq) P.lse[(int64_t)bh * nq + i] = mx + __logf(sum);
+      // O[i][c] = sum_j P[i][j] V[j][c]: A = the score registers, B = V[j = 16 jt + 4 g + r][16 ct + lane&15]
+      f32x4 o[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jt = 0; jt < NKE; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) o[ct] = mfma4(st[jt][r], vc[jt][r][ct], o[ct]);
+      // the result tile: col = channel 16 ct + lane&15, row = query 16 it + 4 g + r; 1/sum belongs to the ROW's query
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int io = 16 * it + 4 * g + r;
+        const float invr = __shfl(inv, 4 * g + r, 64);   // lane (4 g + r) of group 0 holds query 16 it + 4 g + r
+        if (io < nq) {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const int c = 16 * ct + r15;
+            if (DK >= 16 || c < DK) Ob[(int64_t)io * P.ldo + c] = o[ct][r] * invr;
+          }
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) qf[s] = qn[s];
+        dbits = dnext;
       }
     }
-  }
+  };
+  if (NKT >= 4 && nkt_e >= 4) run(std::integral_constant<int, NKT >= 4 ? 4 : 1>{});
+  else if (NKT >= 3 && nkt_e == 3) run(std::integral_constant<int, NKT >= 3 ? 3 : 1>{});
+  else if (NKT >= 2 && nkt_e == 2) run(std::integral_constant<int, NKT >= 2 ? 2 : 1>{});
+  else run(std::integral_constant<int, 1>{});
 }
 
 
