@@ -46,6 +46,11 @@ class Seq2seq(BaseModel):
         key = (device.type, device.index)
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
+            # parameters that still go through AccumulateGrad (main stream) receive gradients from side-stream nodes on
+            # purpose; autograd orders the two streams itself and only warns about the extra synchronisation
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
         return self._streams[key]
 
     # ---- batches (seq2seq.py:108-164) ---------------------------------------------------------
@@ -224,48 +229,56 @@ class Seq2seq(BaseModel):
                 glen = self.get_lengths(idx, eos_idx)
             return soft, glen
 
-        if overlap:
-            with torch.cuda.stream(side):
-                gen_soft_tokens, gen_lengths = transfer_pass()
-            main.wait_stream(side)
-            gen_soft_tokens.record_stream(main)
-            gen_lengths.record_stream(main)
-        else:
+        def cycle_forward():
+            """transfer pass, cycle pass forward and discriminator forward (seq2seq.py:476-528)"""
             gen_soft_tokens, gen_lengths = transfer_pass()
+            cyc_nll, _, cyc_length_losses, cyc_gen_error, _ = model_F(
+                gen_soft_tokens, gen_lengths, inp_tokens, inp_lengths, raw_styles,
+                generate=False, differentiable_decode=False, temperature=temperature, use_inference_z=use_inference_z,
+                nll_targets=inp_tokens)
+            cyc_rec_loss = cyc_nll * token_mask                                    # seq2seq.py:504
+            cyc_rec_loss = cyc_rec_loss.sum() / batch_size
+            cyc_rec_loss = cyc_rec_loss * args.cyc_factor
+            cyc_rec_length_loss = self._length_loss(cyc_length_losses, inp_lengths, batch_size) if args.use_learnable else None
 
-        cyc_nll, _, cyc_length_losses, cyc_gen_error, _ = model_F(
-            gen_soft_tokens, gen_lengths, inp_tokens, inp_lengths, raw_styles,
-            generate=False, differentiable_decode=False, temperature=temperature, use_inference_z=use_inference_z,
-            nll_targets=inp_tokens)
-        cyc_rec_loss = cyc_nll * token_mask                                    # seq2seq.py:504
-        cyc_rec_loss = cyc_rec_loss.sum() / batch_size
-        cyc_rec_loss = cyc_rec_loss * args.cyc_factor
-        cyc_rec_length_loss = self._length_loss(cyc_length_losses, inp_lengths, batch_size) if args.use_learnable else None
-
-        # the discriminator's own parameter gradients are never used by f_step (the reference computes and
-        # discards them: optimizer_D.zero_grad() precedes the next use, seq2seq.py:635), so its weights are
-        # frozen for this forward and the weight-gradient GEMMs are not issued
-        d_params = [p for p in self.net.model_D.parameters() if p.requires_grad]
-        for p in d_params:
-            p.requires_grad_(False)
-        try:
-            adv_log_probs = self.net.model_D(gen_soft_tokens, gen_lengths, rev_styles)
-        finally:
+            # the discriminator's own parameter gradients are never used by f_step (the reference computes and
+            # discards them: optimizer_D.zero_grad() precedes the next use, seq2seq.py:635), so its weights are
+            # frozen for this forward and the weight-gradient GEMMs are not issued
+            d_params = [p for p in self.net.model_D.parameters() if p.requires_grad]
             for p in d_params:
-                p.requires_grad_(True)
-        if args.discriminator_method == 'Multi':
-            adv_labels = rev_styles + 1
+                p.requires_grad_(False)
+            try:
+                adv_log_probs = self.net.model_D(gen_soft_tokens, gen_lengths, rev_styles)
+            finally:
+                for p in d_params:
+                    p.requires_grad_(True)
+            if args.discriminator_method == 'Multi':
+                adv_labels = rev_styles + 1
+            else:
+                adv_labels = torch.ones_like(rev_styles)
+            adv_loss = loss_fn(adv_log_probs, adv_labels)
+            adv_factor = (raw_styles == 0) * args.fw_adv_factor + (raw_styles == 1) * args.bw_adv_factor
+            adv_loss = (adv_loss * adv_factor).sum() / batch_size
+
+            total = cyc_rec_loss + adv_loss
+            if args.use_learnable:
+                total = total + cyc_rec_length_loss
+            return total, cyc_rec_loss, cyc_rec_length_loss, cyc_gen_error, adv_loss
+
+        if overlap:
+            # all of it is issued on the side stream: the transfer pass runs beside the self-reconstruction forward,
+            # the cycle pass forward beside backward #1 (it reads parameters only; backward #1 only adds to .grad)
+            with torch.cuda.stream(side):
+                total, cyc_rec_loss, cyc_rec_length_loss, cyc_gen_error, adv_loss = cycle_forward()
+            # backward #2 runs on the side stream (the stream of its nodes' forward) and adds to the .grad buffers
+            # backward #1 created and filled on the main stream: order the two streams both ways before it starts
+            main.wait_stream(side)
+            side.wait_stream(main)
         else:
-            adv_labels = torch.ones_like(rev_styles)
-        adv_loss = loss_fn(adv_log_probs, adv_labels)
-        adv_factor = (raw_styles == 0) * args.fw_adv_factor + (raw_styles == 1) * args.bw_adv_factor
-        adv_loss = (adv_loss * adv_factor).sum() / batch_size
+            total, cyc_rec_loss, cyc_rec_length_loss, cyc_gen_error, adv_loss = cycle_forward()
 
         self.reducer_F.arm("f_full", streams=(main, side) if overlap else ())
-        if args.use_learnable:
-            (cyc_rec_loss + adv_loss + cyc_rec_length_loss).backward()
-        else:
-            (cyc_rec_loss + adv_loss).backward()
+        total.backward()
         if overlap:
             # autograd ran the transfer pass's backward nodes on the side stream (the stream of their forward) and
             # joins only the streams of AccumulateGrad nodes at the end of backward; the kernels here accumulate
