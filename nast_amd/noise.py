@@ -70,9 +70,8 @@ class NoiseLayer(nn.Module):
         src = np.maximum(src, np.arange(-M, 0)[:, None] + l[None, :])                      # the tail must still fit
         past_end = src >= l[None, :]
         l_new = (~past_end).sum(0)
-        for i in range(B):
-            if l_new[i] > 1 and not orig[l_new[i] - 1, i]:
-                l_new[i] -= 1
+        last_inserted = ~orig[np.maximum(l_new - 1, 0), np.arange(B)]                      # never end on an inserted word
+        l_new = l_new - ((l_new > 1) & last_inserted)
         src = np.minimum(src, l[None, :] - 1)
         out = np.take_along_axis(x, src, 0)
         out = np.where(orig, out, new_words)
@@ -86,23 +85,28 @@ class NoiseLayer(nn.Module):
         B = x.shape[1]
         keep = u_keep >= self.dropout_prob
         adv = np.concatenate([np.zeros((1, B), dtype=np.int64), np.cumsum(u_repeat >= self.repeat_prob, 0)], 0)
-        sents = []
-        for i in range(B):
-            n = l[i] - 1 if x[l[i] - 1, i] == self.eos_index else l[i]
-            words = x[:n, i]
-            kept = words[keep[:n, i]]
-            if kept.size == 0:
-                kept = words[pick(n):][:1]
-            idx = np.maximum(adv[:, i], np.arange(-M, 0) + kept.size)
-            out = kept[idx[idx < kept.size]].tolist()
-            if len(out) < M and out[-1] != self.eos_index:
-                out.append(self.eos_index)
-            sents.append(out)
-        l2 = np.array([len(s) for s in sents], dtype=np.int64)
-        x2 = np.full((l2.max(), B), self.pad_index, dtype=np.int64)
-        for i, s in enumerate(sents):
-            x2[:len(s), i] = s
-        return x2, l2
+        # whole-batch form of the reference's per-sentence loop (same draws, same results; the loop costs 3 ms at 512
+        # sentences while the GPU waits for these inputs)
+        S = x.shape[0]
+        cols = np.arange(B)
+        n = np.where(x[l - 1, cols] == self.eos_index, l - 1, l)                          # words before the final <eos>
+        km = keep[:S] & (np.arange(S)[:, None] < n[None, :])
+        order = np.argsort(~km, axis=0, kind="stable")                                     # kept positions first, in order
+        kept = np.take_along_axis(x, order, 0)
+        ksz = km.sum(0)
+        for i in np.nonzero(ksz == 0)[0]:                                                  # every word dropped: keep one
+            kept[0, i] = x[pick(n[i]), i]
+            ksz[i] = 1
+        idx = np.maximum(adv, np.arange(-M, 0)[:, None] + ksz[None, :])                    # [M,B], non-decreasing per column
+        cnt = (idx < ksz[None, :]).sum(0)
+        out = np.take_along_axis(kept, np.minimum(idx, ksz[None, :] - 1)[:, :], 0) if S >= 1 else kept
+        x2 = np.full((M + 1, B), self.pad_index, dtype=np.int64)
+        x2[:M] = out
+        x2[np.arange(M + 1)[:, None] >= cnt[None, :]] = self.pad_index
+        add_eos = (cnt < M) & (x2[cnt - 1, cols] != self.eos_index)
+        x2[cnt[add_eos], cols[add_eos]] = self.eos_index
+        l2 = cnt + add_eos
+        return np.ascontiguousarray(x2[:l2.max()]), l2.astype(np.int64)
 
     def shuffle_apply(self, x, l, noise):
         """Local shuffle: sort positions by index + noise (noise.py:196-230)."""
