@@ -4,14 +4,20 @@
 
 __global__ __launch_bounds__(256) void nast_multi_sqnorm_kernel(const float* const* __restrict__ grads,
                                                                 const int64_t* __restrict__ sizes, float* __restrict__ out_sq) {
-  __shared__ float red[4];
+  __shared__ double red[4];
   const float* g = grads[blockIdx.y];
   const int64_t n = sizes[blockIdx.y];
-  float s = 0.f;
+  double s = 0.0;                                // fp64 partial sums: the kernel is memory-bound, the adds are free
   if (g)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += g[i] * g[i];
-  s = block_sum<256>(s, red);
-  if (threadIdx.x == 0 && s != 0.f) atomicAdd(out_sq, s);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)g[i] * (double)g[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = red[0] + red[1] + red[2] + red[3];
+    if (t != 0.0) atomicAdd(out_sq, (float)t);
+  }
 }
 
 __global__ __launch_bounds__(256) void nast_multi_adam_kernel(float* const* __restrict__ params, float* const* __restrict__ grads,
@@ -30,17 +36,24 @@ __global__ __launch_bounds__(256) void nast_multi_adam_kernel(float* const* __re
     // torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (norm + 1e-6), max=1)
     coef = fminf(max_norm / (sqrtf(*total_sq) + 1e-6f), 1.f);
   }
+  // operation order of torch.optim.Adam (_single_tensor_adam): exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g,
+  // value=1-b2); denom = exp_avg_sq.sqrt() / sqrt(bias_c2) + eps; p.addcdiv_(exp_avg, denom, value=-lr/bias_c1)
   const float step = lr / bias_c1;
-  const float rs2 = 1.f / sqrtf(bias_c2);
+  const float bc2_sqrt = sqrtf(bias_c2);
+  const float w1 = 1.f - beta1, w2 = 1.f - beta2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float gi = g[i] * coef;
-    g[i] = gi;                                   // clip_grad_norm_ scales .grad in place
+    float gi = g[i];
+    if (total_sq) {
+      gi *= coef;
+      g[i] = gi;                                 // clip_grad_norm_ scales .grad in place
+    }
     if (weight_decay != 0.f) gi += weight_decay * p[i];
-    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    const float m0 = m[i];
+    const float mi = m0 + w1 * (gi - m0);
+    const float vi = v[i] * beta2 + (w2 * gi) * gi;
     m[i] = mi;
     v[i] = vi;
-    p[i] -= step * mi / (sqrtf(vi) * rs2 + eps);
+    p[i] += -step * (mi / (sqrtf(vi) / bc2_sqrt + eps));
   }
 }
 

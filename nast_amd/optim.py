@@ -1,0 +1,88 @@
+"""Gradient-norm clip + Adam for a whole parameter group in three launches.
+
+The reference steps each group with `clip_grad_norm_(params, 5)` followed by `torch.optim.Adam.step()`
+(seq2seq.py:35-36, :536-537, :637-638): ~340 tensors -> several hundred tiny launches per step.  `FusedAdam` is a
+`torch.optim.Adam` subclass (same constructor, same `state_dict()` layout: step / exp_avg / exp_avg_sq per parameter, so
+reference checkpoints load) whose `clip_and_step` runs `nast_multi_sqnorm_f32` + `nast_multi_adam_f32` over device
+arrays of tensor pointers.  Arithmetic follows torch's single-tensor Adam operation by operation (optim.hip).
+
+Supported: amsgrad=False, maximize=False, one learning rate per group (what the reference uses); anything else raises.
+CPU parameters (host-only unit tests) take torch's own path.
+"""
+import math
+
+import torch
+from torch import optim
+from torch.nn.utils import clip_grad_norm_
+
+from . import ops
+
+
+class FusedAdam(optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **kw):
+        if kw.get("amsgrad") or kw.get("maximize") or kw.get("capturable") or kw.get("differentiable"):
+            raise NotImplementedError("FusedAdam: amsgrad / maximize / capturable / differentiable are not supported")
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self._tables = {}
+
+    # -- pointer tables (rebuilt only when a tensor moved) -----------------------------------
+    def _table(self, gi, group, plist):
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
+                    for p in plist)
+        ent = self._tables.get(gi)
+        if ent is None or ent[0] != key:
+            dev = plist[0].device
+            cols = list(zip(*key))
+            ptrs = torch.tensor(cols, dtype=torch.int64).to(dev)                  # [4, n] device pointers
+            sizes = torch.tensor([p.numel() for p in plist], dtype=torch.int64).to(dev)
+            sq = torch.zeros(1, device=dev, dtype=torch.float32)
+            ent = (key, ptrs, sizes, sq)
+            self._tables[gi] = ent
+        return ent
+
+    @torch.no_grad()
+    def clip_and_step(self, max_norm=None):
+        """clip_grad_norm_(all parameters of the optimizer, max_norm) (skipped when None), then Adam.  Returns the
+        total gradient norm as a 0-d device tensor (None without clipping)."""
+        plists = [[p for p in g["params"] if p.grad is not None] for g in self.param_groups]
+        flat = [p for pl in plists for p in pl]
+        if not flat:
+            return None
+        if not flat[0].is_cuda:
+            norm = clip_grad_norm_(flat, max_norm) if max_norm is not None else None
+            super().step()
+            return norm
+        for p in flat:
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous() or p.grad.is_sparse:
+                raise NotImplementedError("FusedAdam: contiguous dense fp32 parameters and gradients only")
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        stream = ops._stream()
+        tabs = [self._table(gi, g, pl) if pl else None for gi, (g, pl) in enumerate(zip(self.param_groups, plists))]
+        sq = None
+        if max_norm is not None:
+            sq = next(t for t in tabs if t is not None)[3]
+            sq.zero_()
+            for t in tabs:
+                if t is not None:
+                    _, ptrs, sizes, _ = t
+                    ops.call("nast_multi_sqnorm_f32", ptrs[1].data_ptr(), sizes.data_ptr(), sizes.numel(), sq.data_ptr(), stream)
+        for g, pl, t in zip(self.param_groups, plists, tabs):
+            if t is None:
+                continue
+            steps = {float(self.state[p]["step"]) for p in pl}
+            if len(steps) != 1:
+                raise NotImplementedError("FusedAdam: parameters of one group must share their step count")
+            step = steps.pop() + 1
+            for p in pl:
+                self.state[p]["step"] += 1
+            b1, b2 = g["betas"]
+            _, ptrs, sizes, _ = t
+            ops.call("nast_multi_adam_f32", ptrs[0].data_ptr(), ptrs[1].data_ptr(), ptrs[2].data_ptr(), ptrs[3].data_ptr(),
+                     sizes.data_ptr(), sizes.numel(), sq.data_ptr() if sq is not None else None,
+                     float(max_norm) if max_norm is not None else 0.0, float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                     float(g["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, stream)
+        return sq.sqrt().reshape(()) if sq is not None else None

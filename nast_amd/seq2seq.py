@@ -12,10 +12,10 @@ RCCL, fired once per step during the LAST backward so that it overlaps with it) 
 import numpy as np
 import torch
 from torch import nn, optim
-from torch.nn.utils import clip_grad_norm_
 
 from . import ops
 from .ddp import GradReducer
+from .optim import FusedAdam
 from .transformer import Network
 from .utils import Storage, BaseModel, LongTensor, cuda, generateMask
 from .utils.gumbel import gumbel_soft_and_index
@@ -31,8 +31,12 @@ class Seq2seq(BaseModel):
         net = Network(param)
         if args.radam:
             raise NotImplementedError("--radam: utils/optimizer.py is out of scope (SURVEY.md section 2.1 row 8)")
-        self.optimizer_F = optim.Adam(net.get_parameters_by_name("F"), lr=args.lr_F, weight_decay=args.L2)
-        self.optimizer_D = optim.Adam(net.get_parameters_by_name("D"), lr=args.lr_D, weight_decay=args.L2)
+        # torch.optim.Adam subclasses (same state_dict): clip + step of a whole group in three launches
+        self.optimizer_F = FusedAdam(net.get_parameters_by_name("F"), lr=args.lr_F, weight_decay=args.L2)
+        self.optimizer_D = FusedAdam(net.get_parameters_by_name("D"), lr=args.lr_D, weight_decay=args.L2)
+        for opt, mod in ((self.optimizer_F, net.model_F), (self.optimizer_D, net.model_D)):
+            # the reference clips model.parameters() and steps the optimizer's group (seq2seq.py:536-537): the same tensors
+            assert {id(p) for g in opt.param_groups for p in g["params"]} == {id(p) for p in mod.parameters()}
         super().__init__(param, net, {"optimizer_F": self.optimizer_F, "optimizer_D": self.optimizer_D})
         self.reducer_F = GradReducer(list(self.net.model_F.parameters()))
         self.reducer_D = GradReducer(list(self.net.model_D.parameters()))
@@ -220,7 +224,7 @@ class Seq2seq(BaseModel):
 
         if not cyc_rec_enable:                                                 # seq2seq.py:471-474 (no clipping here)
             self.reducer_F.finish()
-            self.optimizer_F.step()
+            self.optimizer_F.clip_and_step(None)
             self.net.model_D.train()
             return slf_rec_loss.item(), 0, 0, item(slf_rec_length_loss), 0, item(slf_gen_error), 0
 
@@ -291,8 +295,7 @@ class Seq2seq(BaseModel):
             main.wait_stream(side)
         self.reducer_F.finish()
 
-        self.last_grad_norm = clip_grad_norm_(self.net.model_F.parameters(), 5)
-        self.optimizer_F.step()
+        self.last_grad_norm = self.optimizer_F.clip_and_step(5)                # seq2seq.py:536-537
         self.net.model_D.train()
 
         return slf_rec_loss.item(), cyc_rec_loss.item(), adv_loss.item(), \
@@ -351,7 +354,6 @@ class Seq2seq(BaseModel):
         self.reducer_D.arm("d")
         adv_loss.backward()
         self.reducer_D.finish()
-        self.last_grad_norm = clip_grad_norm_(model_D.parameters(), 5)
-        self.optimizer_D.step()
+        self.last_grad_norm = self.optimizer_D.clip_and_step(5)                # seq2seq.py:637-638
         model_F.train()
         return adv_loss.item()

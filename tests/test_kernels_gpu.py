@@ -381,3 +381,46 @@ def test_step_bf16_variant_vs_oracle():
         got, ref, gn, gn_ref = _oracle_vs_hip_step(dict(V=9600, d=256, h=4, N=4, L=32, learnable=True), B=6, seed=3)
     np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-3)
     np.testing.assert_allclose(gn, gn_ref, rtol=5e-2)
+
+
+@pytest.mark.parametrize("max_norm,wd", [(5.0, 0.0), (0.05, 0.0), (None, 0.0), (5.0, 1e-3)])
+def test_fused_adam_matches_torch(ops, max_norm, wd):
+    """FusedAdam.clip_and_step == clip_grad_norm_ + torch.optim.Adam.step over several steps (seq2seq.py:536-537),
+    incl. a parameter that never gets a gradient (sos_token, transformer.py:41) and the same state_dict layout."""
+    from nast_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(9600, 64), (256, 256), (256,), (1024, 256), (7,), (1,)]
+    ref = [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
+    got = [dev(t.detach().clone()).requires_grad_(True) for t in ref]
+    o_ref = torch.optim.Adam(ref, lr=1e-3, weight_decay=wd)
+    o_got = FusedAdam(got, lr=1e-3, weight_decay=wd)
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ref, got)):
+            if i == len(ref) - 1:
+                continue                      # never receives a gradient
+            gr = torch.randn(a.shape, generator=g) * (10.0 if step == 1 else 0.1)
+            a.grad = gr.clone()
+            b.grad = dev(gr.clone())
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, max_norm) if max_norm is not None else None
+        o_ref.step()
+        n_got = o_got.clip_and_step(max_norm)
+        if max_norm is not None:
+            np.testing.assert_allclose(float(n_got), float(n_ref), rtol=1e-5)
+            for a, b in zip(ref[:-1], got[:-1]):
+                relclose(b.grad, a.grad, 1e-5)                 # clipped in place like clip_grad_norm_
+        for a, b in zip(ref, got):
+            x, y = b.detach().cpu().numpy(), a.detach().numpy()
+            if wd == 0.0:
+                np.testing.assert_allclose(x, y, rtol=1e-5, atol=2e-7)
+            else:
+                # where grad + wd * p nearly cancels, Adam's m / sqrt(v) turns the 1e-5 rounding of the clip coefficient into
+                # an O(lr) difference (ill-conditioned in torch itself): allow a few such elements, bounded by lr per step
+                bad = ~np.isclose(x, y, rtol=1e-5, atol=2e-7)
+                assert bad.mean() < 1e-4 and np.abs(x - y).max() <= 2e-3 * (step + 1)
+    sd_ref, sd_got = o_ref.state_dict(), o_got.state_dict()
+    assert sd_ref["state"].keys() == sd_got["state"].keys()
+    for k in sd_ref["state"]:
+        assert sd_ref["state"][k].keys() == sd_got["state"][k].keys()
+        assert float(sd_ref["state"][k]["step"]) == float(sd_got["state"][k]["step"])
+        # the clip coefficient carries the rounding of two different fp32 reductions of ~3e6 squares (norms agree to 1e-5)
+        np.testing.assert_allclose(sd_got["state"][k]["exp_avg_sq"].cpu().numpy(), sd_ref["state"][k]["exp_avg_sq"].numpy(), rtol=5e-5, atol=1e-12)
