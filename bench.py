@@ -205,6 +205,17 @@ def main():
         # the discriminator step (seq2seq.py:551-642) on the same batches
         dt = timed(lambda i: model.d_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
         also["d_step"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B}
+        f_ms = elapsed / a.steps
+        # the reference schedule runs 10 d_step per 5 f_step (run.py:133-134)
+        also["schedule_blend_10d_5f"] = {"value": round(15 * B / (10 * dt + 5 * f_ms), 2), "unit": "sentences/s"}
+        # ... and the step without its optimizer (clip + Adam skipped; forward + both backwards only)
+        step_fn = model.optimizer_F.clip_and_step
+        model.optimizer_F.clip_and_step = lambda max_norm=None: None
+        try:
+            dt_fb = timed(lambda i: model.f_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
+        finally:
+            model.optimizer_F.clip_and_step = step_fn
+        also["fwd_bwd_only"] = {"value": round(B / dt_fb, 2), "unit": "sentences/s", "ms_per_step": round(dt_fb * 1e3, 3), "batch": B}
         # BASELINE.json configs[1]: simple alignment, YELP-shaped batch (64 sentences, len <= 16)
         cfg1 = dict(V=9600, d=256, h=4, N=4, L=16, learnable=False)
         m1 = build_model(cfg1, "cuda")
@@ -238,10 +249,20 @@ def main():
         lib.nast_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
         if rank == 0 and ms.value > 0:
             ach = fl.value / (ms.value * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "nast_gemm_f32_kernel", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+            roofline = {"bound": "mfma", "kernel": "nast_gemm_f32_kernel (tiled fp32 MFMA GEMM, 78 % of kernel time)",
+                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                         "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
                         "avg_launch_gflop": round(fl.value / max(n.value, 1) / 1e9, 4)}
+            # the small-M GEMM kernel of the greedy decode (M = sentences, latency-bound) and the family as a whole
+            ms4, fl4, n4 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            lib.nast_prof_get(4, ctypes.byref(ms4), ctypes.byref(fl4), ctypes.byref(n4))
+            if ms4.value > 0:
+                roofline["decode_small_m_gemm"] = {"achieved": round(fl4.value / (ms4.value * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                                   "launches": int(n4.value), "avg_launch_us": round(ms4.value * 1e3 / max(n4.value, 1), 2)}
+                allf = (fl.value + fl4.value) / ((ms.value + ms4.value) * 1e-3) / 1e12
+                roofline["gemm_family_all"] = {"achieved": round(allf, 2), "frac": round(allf / PEAK_FP32_MFMA_TFLOPS, 4),
+                                               "launches": int(n.value + n4.value)}
             # the HBM-bound families next to it: algorithmic bytes / HIP-event time
             hbm = {}
             for kind, name in ((2, "vocab_row_kernels"), (3, "alignment_dp")):
@@ -257,7 +278,7 @@ def main():
             if B == 512 and learnable and os.path.exists(tpath):
                 with open(tpath) as f:
                     t = json.load(f)
-                fams = [t[k] for k in ("nast_gemm_f32_kernel", "nast_gemm_f32_skinny_kernel") if k in t]
+                fams = [t[k] for k in ("nast_gemm_f32_kernel",) if k in t]
                 if fams:
                     roofline["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
                     roofline["traffic_unit"] = "bytes per launch, PMC passes recorded in profiles/r1_pmc_traffic.txt"

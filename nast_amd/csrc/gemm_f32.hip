@@ -741,7 +741,8 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
     NAST_REQUIRE(descs[i].ln_gamma == nullptr || skinny, "nast_gemm_f32[%d]: fused LayerNorm needs the small-M path (M<=1024, K<=256, x W^T)", i);
   int tilesL = 0;
   plan_and_launch<128, 128, NAST_BK128>(descs, count, stream, true, &tilesL);
-  nast_prof_before(1, stream);
+  const int prof_kind = skinny ? 4 : 1;
+  nast_prof_before(prof_kind, stream);
   if (skinny) launch_skinny(descs, count, stream);
   else {
     static const int force = [] { const char* e = getenv("NAST_GEMM_TILE"); return e ? atoi(e) : -1; }();   // tuning aid
@@ -753,7 +754,7 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
     if (cfg == 2) plan_and_launch<128, 128, NAST_BK128>(descs, count, stream, false, nullptr);
     else plan_and_launch<64, 64, 32>(descs, count, stream, false, nullptr);
   }
-  if (nast_prof_shapes(1)) {
+  if (nast_prof_shapes(prof_kind)) {
     std::string sig = skinny ? "skinny" : (tilesL >= 4096 ? "t128" : "t64");
     for (int i = 0; i < count; ++i) {
       const nast_gemm_desc& d = descs[i];
@@ -762,9 +763,9 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
                d.bias ? " b" : "", d.residual ? " r" : "", d.colsum ? " cs" : "", d.ln_gamma ? " ln" : "");
       sig += b;
     }
-    nast_prof_after(1, stream, flops, sig.c_str());
+    nast_prof_after(prof_kind, stream, flops, sig.c_str());
   } else {
-    nast_prof_after(1, stream, flops);
+    nast_prof_after(prof_kind, stream, flops);
   }
   NAST_CHECK_LAUNCH("nast_gemm_f32");
   return NAST_OK;
