@@ -45,6 +45,7 @@ class Seq2seq(BaseModel):
     _streams = None
 
     overlap_min_tokens = 4096
+    merge_generate_max = 1024   # d_step: generate both styles as one batch while 2B stays on the decode's small-M path
 
     def _side_stream(self, device):
         if self._streams is None:
@@ -316,12 +317,28 @@ class Seq2seq(BaseModel):
         model_F, model_D = self.net.model_F, self.net.model_D
 
         with torch.no_grad():
-            raw_gen_log_probs, raw_gen_lengths, _, _, _ = model_F(
-                inp_tokens, inp_lengths, None, None, raw_styles, generate=True, differentiable_decode=True,
-                temperature=temperature, use_inference_z=use_inference_z)
-            rev_gen_log_probs, rev_gen_lengths, _, _, _ = model_F(
-                inp_tokens, inp_lengths, None, None, rev_styles, generate=True, differentiable_decode=True,
-                temperature=temperature, use_inference_z=use_inference_z)
+            if inp_tokens.is_cuda and 2 * batch_size <= self.merge_generate_max:
+                # The two generation passes (seq2seq.py:565-580) differ only in the style token: they run as ONE batch of
+                # 2B sentences -- every op is per sentence, and the greedy skip decoding (latency-bound: ~800 small
+                # dependent launches) is paid once instead of twice.  Each half is then cut back to its own width
+                # (max generated length of that half), which is what the separate calls return.
+                both_log_probs, both_lengths, _, _, _ = model_F(
+                    torch.cat((inp_tokens, inp_tokens), 0), torch.cat((inp_lengths, inp_lengths), 0), None, None,
+                    torch.cat((raw_styles, rev_styles), 0), generate=True, differentiable_decode=True,
+                    temperature=temperature, use_inference_z=use_inference_z)
+                raw_gen_log_probs, rev_gen_log_probs = both_log_probs[:batch_size], both_log_probs[batch_size:]
+                raw_gen_lengths = rev_gen_lengths = None
+                if both_lengths is not None:
+                    raw_gen_lengths, rev_gen_lengths = both_lengths[:batch_size], both_lengths[batch_size:]
+                    t_raw, t_rev = torch.stack((raw_gen_lengths.max(), rev_gen_lengths.max())).tolist()
+                    raw_gen_log_probs, rev_gen_log_probs = raw_gen_log_probs[:, :t_raw], rev_gen_log_probs[:, :t_rev]
+            else:
+                raw_gen_log_probs, raw_gen_lengths, _, _, _ = model_F(
+                    inp_tokens, inp_lengths, None, None, raw_styles, generate=True, differentiable_decode=True,
+                    temperature=temperature, use_inference_z=use_inference_z)
+                rev_gen_log_probs, rev_gen_lengths, _, _, _ = model_F(
+                    inp_tokens, inp_lengths, None, None, rev_styles, generate=True, differentiable_decode=True,
+                    temperature=temperature, use_inference_z=use_inference_z)
 
         raw_gen_soft_tokens, raw_idx = self._approx_with_index(raw_gen_log_probs, args.dis_approx_mode)
         if not args.use_learnable:
