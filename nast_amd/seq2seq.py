@@ -316,6 +316,23 @@ class Seq2seq(BaseModel):
         batch_size = inp_tokens.size(0)
         model_F, model_D = self.net.model_F, self.net.model_D
 
+        # The discriminator's forward on the gold sentences needs nothing from the generator: it is issued on the second
+        # stream first, so it fills the CUs that the latency-bound generation (greedy decode) leaves idle.
+        overlap = self.overlap_passes and inp_tokens.is_cuda and inp_tokens.numel() >= self.overlap_min_tokens
+
+        def gold_forward():
+            if args.discriminator_method == 'Multi':
+                return model_D(inp_tokens, inp_lengths), raw_styles + 1
+            return (torch.cat((model_D(inp_tokens, inp_lengths, raw_styles), model_D(inp_tokens, inp_lengths, rev_styles)), 0),
+                    torch.cat((torch.ones_like(raw_styles), torch.zeros_like(rev_styles)), 0))
+
+        if overlap:
+            main = torch.cuda.current_stream()
+            side = self._side_stream(inp_tokens.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gold_log_probs, gold_labels = gold_forward()
+
         with torch.no_grad():
             if inp_tokens.is_cuda and 2 * batch_size <= self.merge_generate_max:
                 # The two generation passes (seq2seq.py:565-580) differ only in the style token: they run as ONE batch of
@@ -347,20 +364,21 @@ class Seq2seq(BaseModel):
         if not args.use_learnable:
             rev_gen_lengths = self.get_lengths(rev_idx, eos_idx)
 
+        if not overlap:
+            gold_log_probs, gold_labels = gold_forward()
         if args.discriminator_method == 'Multi':
-            gold_log_probs = model_D(inp_tokens, inp_lengths)
-            gold_labels = raw_styles + 1
             gen_log_probs = torch.cat((model_D(raw_gen_soft_tokens, raw_gen_lengths),
                                        model_D(rev_gen_soft_tokens, rev_gen_lengths)), 0)
             gen_labels = torch.cat((raw_styles + 1, torch.zeros_like(rev_styles)), 0)
         else:
-            gold_log_probs = torch.cat((model_D(inp_tokens, inp_lengths, raw_styles),
-                                        model_D(inp_tokens, inp_lengths, rev_styles)), 0)
-            gold_labels = torch.cat((torch.ones_like(raw_styles), torch.zeros_like(rev_styles)), 0)
             gen_log_probs = torch.cat((model_D(raw_gen_soft_tokens, raw_gen_lengths, raw_styles),
                                        model_D(rev_gen_soft_tokens, rev_gen_lengths, rev_styles)), 0)
             gen_labels = torch.cat((torch.ones_like(raw_styles), torch.zeros_like(rev_styles)), 0)
 
+        if overlap:
+            main.wait_stream(side)              # the gold half of the loss comes from the side stream
+            gold_log_probs.record_stream(main)
+            gold_labels.record_stream(main)
         adv_log_probs = torch.cat((gold_log_probs, gen_log_probs), 0)
         adv_labels = torch.cat((gold_labels, gen_labels), 0)
         adv_loss = loss_fn(adv_log_probs, adv_labels)
@@ -368,8 +386,12 @@ class Seq2seq(BaseModel):
         adv_loss = adv_loss.sum() / batch_size
 
         self.optimizer_D.zero_grad(set_to_none=False)
-        self.reducer_D.arm("d")
+        if overlap:
+            side.wait_stream(main)              # its backward nodes add to the .grad buffers zeroed just above
+        self.reducer_D.arm("d", streams=(main, side) if overlap else ())
         adv_loss.backward()
+        if overlap:
+            main.wait_stream(side)              # explicit join, as in f_step (no AccumulateGrad node lives on the side stream)
         self.reducer_D.finish()
         self.last_grad_norm = self.optimizer_D.clip_and_step(5)                # seq2seq.py:637-638
         model_F.train()
