@@ -704,7 +704,11 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
   }
   P = Q;
   static const int xcd_order = [] { const char* e = getenv("NAST_GEMM_XCD"); return e ? atoi(e) : 0; }();   // tuning aid
-  P.xcd_order = xcd_order;
+  // 2 = only for launches whose workgroups all do the same amount of work (one problem, or equal unsplit problems)
+  bool uniform = true;
+  for (int i = 0; i < count; ++i)
+    uniform = uniform && P.splitk[i] == 1 && P.d[i].M == P.d[0].M && P.d[i].N == P.d[0].N && P.d[i].K == P.d[0].K && P.d[i].nsrc == P.d[0].nsrc;
+  P.xcd_order = xcd_order == 2 ? (uniform ? 1 : 0) : xcd_order;
   for (int i = count; i <= NAST_GEMM_MAX_GROUP; ++i) P.tile_start[i] = start;
   if (start == 0) return 0;
   bool bf16 = true;

@@ -22,7 +22,9 @@ from nast_amd.seq2seq import Seq2seq
 from nast_amd.utils import Storage
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-learnable = sys.argv[2] == "learnable"
+learnable = sys.argv[2].startswith("learnable")
+if sys.argv[2].endswith("2streams"):          # the second-stream overlap that production batches (>= 4096 tokens) use
+    Seq2seq.overlap_min_tokens = 0
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cfg = dict(V=48, d=32, h=4, N=2, L=8, learnable=learnable, gen_approx_mode="soft", dis_approx_mode="soft")
@@ -94,11 +96,11 @@ print("ok", rank)
 '''
 
 
-@pytest.mark.parametrize("mode", ["simple", "learnable"])
+@pytest.mark.parametrize("mode", ["simple", "learnable", "learnable-2streams"])
 def test_two_rank_step_equals_single_process(tmp_path, mode):
     script = tmp_path / "w.py"
     script.write_text(WORKER)
-    port = "29621" if mode == "simple" else "29622"
+    port = {"simple": "29621", "learnable": "29622", "learnable-2streams": "29623"}[mode]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2", OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, mode], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]

@@ -209,15 +209,20 @@ def test_gumbel_api_golden():
 
 @pytest.mark.parametrize("tag", ["simple", "learnable"])
 @pytest.mark.parametrize("mode", ["f_step", "d_step", "f_step_pretrain"])
-def test_training_steps_golden(tag, mode):
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_training_steps_golden(tag, mode, two_streams):
     """Two consecutive steps from the captured weights / batch / noisy batch / Gumbel draws: returned losses,
-    pre-clip gradient norm, clipped gradients and post-Adam weights (seq2seq.py:416-543, :551-642)."""
+    pre-clip gradient norm, clipped gradients and post-Adam weights (seq2seq.py:416-543, :551-642).
+    two_streams forces the second-stream overlap that production batches (>= 4096 tokens) use."""
+    if two_streams and mode == "f_step_pretrain":
+        pytest.skip("the pretrain step has a single pass: nothing to overlap")
     import nast_amd.utils as U
     from nast_amd.seq2seq import Seq2seq
     from nast_amd.utils import Storage
     g = load_golden(f"g9_{tag}_{mode}")
     U.cuda_init(0, "cuda")
     model = Seq2seq(make_param(device="cuda", **cfg_of(g)))
+    model.overlap_min_tokens = 0 if two_streams else 1 << 60
     assert not load_weights(model.net, sub(g, "w0/"))
     model.net.model_F.train(); model.net.model_D.train()
     pref = "model_D." if mode == "d_step" else "model_F."
