@@ -156,9 +156,16 @@ def main():
     np.random.seed(100 + rank)
     torch.cuda.manual_seed(100 + rank)
 
+    debug = os.environ.get("NAST_BENCH_DEBUG")      # rehearsal aid: progress lines + a stack dump if a step stalls
+    if debug:
+        import faulthandler
+        faulthandler.dump_traceback_later(int(debug), repeat=True, file=sys.stderr)
+
     def run(n, offset=0):
         for i in range(n):
             model.f_step(batches[(i + offset) % len(batches)], 1.0, use_inference_z=True)
+            if debug:
+                print(f"[rank {rank}] step {i + 1}/{n} done at {time.perf_counter():.1f}", file=sys.stderr, flush=True)
 
     def fence():
         torch.cuda.synchronize()

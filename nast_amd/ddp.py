@@ -44,7 +44,10 @@ class _Plan:
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=16 << 20, group=None):
+    BUCKET_BYTES = 16 << 20
+
+    def __init__(self, params, bucket_bytes=None, group=None):
+        bucket_bytes = self.BUCKET_BYTES if bucket_bytes is None else bucket_bytes
         self.params = [p for p in params if p.requires_grad]
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.group = group
