@@ -24,8 +24,19 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_dev_index = None
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~9 us of Python per call (3.3 ms per
+    step at 64 sentences, where the step is bound by the host); the raw accessor is a plain C call."""
+    global _dev_index
+    if _raw_stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()      # one process drives one GPU (bench.py / torchrun set it first)
+    return _raw_stream(_dev_index)
 
 
 def _chk(*ts):
