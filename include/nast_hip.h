@@ -107,6 +107,21 @@ int nast_mha_bwd_f32(const float* q, const float* k, const float* v, const uint8
                      int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                      int64_t mask_bs, int64_t mask_qs, float scale, void* stream);
 
+/* Packed ("varlen") rows -- no counterpart in the reference, which pads every sentence to the batch width and masks
+ * (transformer.py:57-63, :296-303): sentence b owns rows q_off[b] .. q_off[b]+q_len[b]-1 of q / out / dq and rows
+ * k_off[b] .. +k_len[b]-1 of k / v / dk / dv (row pitch ld*, heads side by side); every key of a sentence is visible to
+ * every query of it, i.e. exactly what the padding mask leaves.  max_nq, max_nk <= 64 bound the lengths.
+ * lse: [B, h, max_nq].  Used by Encoder/Decoder when they run on packed rows. */
+int nast_mha_fwd_varlen_f32(const float* q, const float* k, const float* v, float* out, float* lse, int B, int h,
+                            int max_nq, int max_nk, int dk, int ldq, int ldk, int ldv, int ldo,
+                            const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len,
+                            float scale, void* stream);
+int nast_mha_bwd_varlen_f32(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+                            float* dq, float* dk, float* dv, int B, int h, int max_nq, int max_nk, int dk_head,
+                            int ldq, int ldk, int ldv, int ldo,
+                            const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len,
+                            float scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Row kernels over the vocabulary axis (HBM-bound): one workgroup per row.
  * Row addressing for x / y:  row r lives at  base + (r / grp) * grp_stride + (r % grp) * ld   (grp = 0:

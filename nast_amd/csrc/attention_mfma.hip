@@ -65,7 +65,28 @@ struct AttnArgs {
   int BH, h, nq, nk, ldq, ldk, ldv, ldo;
   int64_t q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs;
   float scale;
+  // packed ("varlen") rows: sentence b owns rows q_off[b] .. q_off[b]+q_len[b]-1 of q / out / dq and rows
+  // k_off[b] .. +k_len[b]-1 of k / v / dk / dv; nq / nk are then the maxima (they size the tiles) and mask is NULL
+  const int32_t *q_off, *k_off, *q_len, *k_len;
 };
+
+// per-sentence geometry: padded batches use the batch strides, packed ones the offset arrays
+struct SeqGeom {
+  int nq, nk;
+  int64_t q0, k0, v0, o0;
+};
+__device__ __forceinline__ SeqGeom seq_geom(const AttnArgs& P, int b) {
+  SeqGeom g;
+  if (P.q_off != nullptr) {
+    g.nq = P.q_len[b]; g.nk = P.k_len[b];
+    g.q0 = (int64_t)P.q_off[b] * P.ldq; g.o0 = (int64_t)P.q_off[b] * P.ldo;
+    g.k0 = (int64_t)P.k_off[b] * P.ldk; g.v0 = (int64_t)P.k_off[b] * P.ldv;
+  } else {
+    g.nq = P.nq; g.nk = P.nk;
+    g.q0 = b * P.q_bs; g.o0 = b * P.o_bs; g.k0 = b * P.k_bs; g.v0 = b * P.v_bs;
+  }
+  return g;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // One 256-thread workgroup per (sentence, head).  K and V (backward: also Q and dO) are staged once in LDS as
@@ -227,10 +248,12 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r15 = lane & 15, g = lane >> 4;
   const int bh = blockIdx.x;
   const int b = bh / P.h, head = bh % P.h;
-  const int nq = P.nq, nk = P.nk;
-  float* dQb = P.dq + b * P.q_bs + head * DK;
-  float* dKb = P.dk + b * P.k_bs + head * DK;
-  float* dVb = P.dv + b * P.v_bs + head * DK;
+  const SeqGeom G = seq_geom(P, b);
+  const int nq = G.nq, nk = G.nk;
+  if (nq <= 0 || nk <= 0) return;               // (uniform for the workgroup)
+  float* dQb = P.dq + G.q0 + head * DK;
+  float* dKb = P.dk + G.k0 + head * DK;
+  float* dVb = P.dv + G.v0 + head * DK;
   const float scale = P.scale;
   const int nqt = (nq + 15) / 16, nkt = (nk + 15) / 16;
   // Everything the two phases read comes to LDS in ONE global round trip: K, V, Q, dO rows, the log-sum-exp row and
@@ -253,10 +276,10 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
     // all global loads of the four operand images are issued before the first LDS store (one memory round trip)
     constexpr int V4 = DK / 4, CH = (NT * 16 * V4 + 255) / 256;
     float4 rk[CH], rv[CH], rq[CH], rg[CH];
-    const float* Kg = P.k + b * P.k_bs + head * DK;
-    const float* Vg = P.v + b * P.v_bs + head * DK;
-    const float* Qg = P.q + b * P.q_bs + head * DK;
-    const float* Gg = P.dout + b * P.o_bs + head * DK;
+    const float* Kg = P.k + G.k0 + head * DK;
+    const float* Vg = P.v + G.v0 + head * DK;
+    const float* Qg = P.q + G.q0 + head * DK;
+    const float* Gg = P.dout + G.o0 + head * DK;
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       const int c = threadIdx.x + 256 * u, r = c / V4, q = (c % V4) * 4;
@@ -282,7 +305,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
       }
     }
   }
-  for (int i = threadIdx.x; i < nqt * 16; i += 256) lse_s[i] = P.lse_in[(int64_t)bh * nq + (i < nq ? i : nq - 1)];
+  for (int i = threadIdx.x; i < nqt * 16; i += 256) lse_s[i] = P.lse_in[(int64_t)bh * P.nq + (i < nq ? i : nq - 1)];
   // dead-flag bit rows by wave ballots (the bytes were requested before the operand images)
 #pragma unroll
   for (int u = 0; u < NT * 4; ++u) {
@@ -482,11 +505,13 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_wave_kernel(const AttnArgs P
   const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (bh >= P.BH) return;
   const int b = bh / P.h, head = bh % P.h;
-  const int nq = P.nq, nk = P.nk;
-  const float* Kb = P.k + b * P.k_bs + head * DK;
-  const float* Vb = P.v + b * P.v_bs + head * DK;
-  const float* Qb = P.q + b * P.q_bs + head * DK;
-  float* Ob = P.out + b * P.o_bs + head * DK;
+  const SeqGeom G = seq_geom(P, b);
+  const int nq = G.nq, nk = G.nk;
+  if (nq <= 0 || nk <= 0) return;               // (uniform for the wavefront)
+  const float* Kb = P.k + G.k0 + head * DK;
+  const float* Vb = P.v + G.v0 + head * DK;
+  const float* Qb = P.q + G.q0 + head * DK;
+  float* Ob = P.out + G.o0 + head * DK;
   const int nqt = (nq + 15) / 16;
   const bool pad_mask = P.mask != nullptr && P.mask_qs == 0;
   const bool row_mask = P.mask != nullptr && P.mask_qs != 0;
@@ -498,7 +523,7 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_wave_kernel(const AttnArgs P
     const unsigned long long seen = ~dead_row;
     if (seen != 0ull) nk_e = 64 - __clzll((long long)seen);   // all keys masked: plain path (NaN like the reference)
   }
-  const int nkt_e = (nk_e + 15) / 16;
+  const int nkt_e = (nk_e + 15) / 16;           // (packed rows: nk is already the sentence's own length)
 
   auto run = [&](auto nke_c) {
     constexpr int NKE = decltype(nke_c)::value;
@@ -585,7 +610,7 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_wave_kernel(const AttnArgs P
         }
       sum = xor_sum_g(sum);
       const float inv = 1.f / sum;
-      if (g == 0 && i < nq) P.lse[(int64_t)bh * nq + i] = mx + __logf(sum);
+      if (g == 0 && i < nq) P.lse[(int64_t)bh * P.nq + i] = mx + __logf(sum);
       // O[i][c] = sum_j P[i][j] V[j][c]: A = the score registers, B = V[j = 16 jt + 4 g + r][16 ct + lane&15]
       f32x4 o[NCT];
 #pragma unroll
@@ -651,9 +676,11 @@ int launch_bwd_nt(const AttnArgs& A, int nt, hipStream_t s) {
 // Entry points used by attention.hip's dispatcher.  Return 1 when the shape is outside this file's limits.
 int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, float* out, float* lse, int B, int h, int nq,
                       int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
-                      int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s) {
+                      int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s, const int32_t* q_off, const int32_t* k_off,
+                      const int32_t* q_len, const int32_t* k_len) {
   if (nq > 64 || nk > 64) return 1;
   AttnArgs A = {};
+  A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len;
   A.q = q; A.k = k; A.v = v; A.mask = mask; A.out = out; A.lse = lse;
   A.BH = B * h; A.h = h; A.nq = nq; A.nk = nk; A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.ldo = ldo;
   A.q_bs = q_bs; A.k_bs = k_bs; A.v_bs = v_bs; A.o_bs = o_bs; A.mask_bs = mask_bs; A.mask_qs = mask_qs; A.scale = scale;
@@ -669,9 +696,11 @@ int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint
 
 int nast_mha_bwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, const float* dout, const float* lse, float* dq,
                       float* dk_, float* dv, int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs,
-                      int64_t k_bs, int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s) {
+                      int64_t k_bs, int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s,
+                      const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len) {
   if (nq > 64 || nk > 64) return 1;
   AttnArgs A = {};
+  A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len;
   A.q = q; A.k = k; A.v = v; A.mask = mask; A.dout = dout; A.lse_in = lse; A.dq = dq; A.dk = dk_; A.dv = dv;
   A.BH = B * h; A.h = h; A.nq = nq; A.nk = nk; A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.ldo = ldo;
   A.q_bs = q_bs; A.k_bs = k_bs; A.v_bs = v_bs; A.o_bs = o_bs; A.mask_bs = mask_bs; A.mask_qs = mask_qs; A.scale = scale;

@@ -144,4 +144,6 @@ class NoiseLayer(nn.Module):
             u_keep = np.random.rand(M, x.shape[1])
             u_rep = np.random.rand(M - 1, x.shape[1])
             x, l = self.dropout_apply(x, l, u_keep, u_rep, lambda n: np.random.randint(0, n))
-        return torch.from_numpy(np.ascontiguousarray(x)).to(dev), torch.from_numpy(l).to(dev)
+        lengths = torch.from_numpy(l).to(dev)
+        lengths.nast_total = int(l.sum())       # known on the host: lets the packed-row layers skip a device read
+        return torch.from_numpy(np.ascontiguousarray(x)).to(dev), lengths

@@ -411,6 +411,141 @@ def layer_norm_rows(x, gamma, beta, grp, grp_stride, grp_off, rows_out):
     return LayerNormFn.apply(x, gamma, beta, grp, grp_stride, grp_off, rows_out)
 
 
+# ------------------------------------------------------------------------------------------------
+# packed rows: the position-wise work of a ragged batch without its padding
+# ------------------------------------------------------------------------------------------------
+# A [B, n, d] batch of sentences of lengths len[b] <= n spends n - len[b] rows per sentence on padding that every
+# consumer masks (transformer.py:56-61) and that carries no loss and no gradient.  Encoder / Decoder stacks therefore
+# run on the R = sum(len) real rows only ("packed": sentence b owns rows off[b] .. off[b]+len[b]-1): LayerNorm, the
+# projections and the FFN are row-wise, attention uses the packed entry points (nast_mha_*_varlen_f32).  Results on
+# real rows are the padded computation's; padded rows come back as zeros.  Enabled by Seq2seq for its training steps
+# (PACK_ROWS); module-level calls keep the reference's padded behaviour, including the values at padded positions.
+PACK_ROWS = False
+PACK_MAX_LEN = 64            # limit of the packed attention kernels
+
+
+class packed_rows:
+    """with ops.packed_rows(True): ...  switches the packed execution of Encoder / Decoder stacks on."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        global PACK_ROWS
+        self.prev, PACK_ROWS = PACK_ROWS, self.on
+
+    def __exit__(self, *exc):
+        global PACK_ROWS
+        PACK_ROWS = self.prev
+
+
+def set_total(lengths, total):
+    """Remember sum(lengths) (known on the host) on the tensor, so that packing needs no device-to-host read."""
+    lengths.nast_total = int(total)
+    return lengths
+
+
+class PackedSeq:
+    ROW_MULTIPLE = 64        # packed buffers are padded to a multiple of this (weight-gradient GEMMs: K = rows, K % 32 == 0
+    #                          keeps them on the fast path).  Padding rows duplicate row 0 on the way in, are kept finite in
+    #                          the forward pass and carry exactly zero gradient in the backward pass.
+
+    def __init__(self, lengths, width, total=None):
+        """lengths [B] int64 (device), width = n of the padded layout, total = sum(lengths) if the host knows it."""
+        self.B, self.width = lengths.shape[0], width
+        if total is None:
+            total = getattr(lengths, "nast_total", None)
+        if total is None:
+            total = int(lengths.sum())                       # device-to-host read
+        self.total = total
+        self.rows = (total + self.ROW_MULTIPLE - 1) // self.ROW_MULTIPLE * self.ROW_MULTIPLE
+        dev = lengths.device
+        off = torch.cumsum(lengths, 0) - lengths
+        self.len32, self.off32 = lengths.to(torch.int32), off.to(torch.int32)
+        self.off = off
+        self.b_of = torch.repeat_interleave(torch.arange(self.B, device=dev), lengths, output_size=total)
+        self.pos = torch.arange(total, device=dev) - off[self.b_of]
+        self.idx = self.b_of * width + self.pos              # packed row -> row of the padded [B*width] layout
+        self.idx_p = _pad_index(self.idx, self.rows)
+        self._tail = None
+
+    def tail(self):
+        """The rows after each sentence's first one: (their packed row numbers, padded like every packed buffer, and a
+        PackedSeq of lengths-1 / width-1 describing them)."""
+        if self._tail is None:
+            sub = PackedSeq(self.len32.to(torch.int64) - 1, self.width - 1, self.total - self.B)
+            self._tail = (_pad_index(self.off[sub.b_of] + sub.pos + 1, sub.rows), sub)
+        return self._tail
+
+
+def _pad_index(idx, rows):
+    if rows == idx.shape[0]:
+        return idx
+    return torch.cat((idx, idx.new_zeros(rows - idx.shape[0])))
+
+
+class PackedPair:
+    """query-side and key-side layouts of one attention call"""
+
+    def __init__(self, q, k):
+        self.q, self.k = q, k
+
+
+def packed_of(mask, x):
+    """PackedSeq for a padding mask made by transformer._pad_mask, or None when packing does not apply."""
+    if not PACK_ROWS or mask is None or not x.is_cuda:
+        return None
+    ps = getattr(mask, "nast_packed", None)
+    if ps is not None:
+        return ps
+    src = getattr(mask, "nast_lengths", None)
+    if src is None or mask.shape[-1] > PACK_MAX_LEN:
+        return None
+    lengths, extra = src
+    total = getattr(lengths, "nast_total", None)
+    ps = PackedSeq(lengths + extra, mask.shape[-1], None if total is None else total + extra * lengths.shape[0])
+    mask.nast_packed = ps
+    return ps
+
+
+def pack_rows(x, ps):
+    """[B, n, d] -> [ps.rows, d]  (ps.total real rows, then copies of row 0 as padding)"""
+    return x.reshape(-1, x.shape[-1]).index_select(0, ps.idx_p)
+
+
+def unpack_rows(xp, ps):
+    """[ps.rows, d] -> [B, n, d], zeros at the padded positions"""
+    out = torch.zeros(ps.B * ps.width, xp.shape[-1], device=xp.device, dtype=xp.dtype)
+    return out.index_copy(0, ps.idx, xp[:ps.total]).view(ps.B, ps.width, xp.shape[-1])
+
+
+def mha_fwd_packed(q, k, v, pair, h):
+    """q [Rq, D], k/v [Rk, D] packed -> out [Rq, D], lse [B, h, max_nq]"""
+    D = q.shape[1]
+    dk = D // h
+    B = pair.q.B
+    out = torch.empty_like(q)
+    lse = torch.empty(B, h, pair.q.width, device=q.device, dtype=F32)
+    call("nast_mha_fwd_varlen_f32", _p(q), _p(k), _p(v), _p(out), _p(lse), B, h, pair.q.width, pair.k.width, dk, D, D, D, D,
+         _p(pair.q.off32), _p(pair.k.off32), _p(pair.q.len32), _p(pair.k.len32), 1.0 / math.sqrt(dk), _stream())
+    if out.shape[0] > pair.q.total:
+        out[pair.q.total:].zero_()                 # padding rows belong to no sentence: keep them finite
+    return out, lse
+
+
+def mha_bwd_packed(q, k, v, pair, h, dout, lse):
+    D = q.shape[1]
+    dk = D // h
+    dq, dk_, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    call("nast_mha_bwd_varlen_f32", _p(q), _p(k), _p(v), _p(dout), _p(lse), _p(dq), _p(dk_), _p(dv), pair.q.B, h, pair.q.width,
+         pair.k.width, dk, D, D, D, D, _p(pair.q.off32), _p(pair.k.off32), _p(pair.q.len32), _p(pair.k.len32),
+         1.0 / math.sqrt(dk), _stream())
+    for t, ps in ((dq, pair.q), (dk_, pair.k), (dv, pair.k)):
+        if t.shape[0] > ps.total:
+            t[ps.total:].zero_()                   # ... and their gradient exactly zero
+    return dq, dk_, dv
+
+
 class AttentionFn(torch.autograd.Function):
     """scaled_attention on [B,n,h*dk] projections (transformer.py:296-303 + the transposes of :287-292)."""
 
@@ -445,30 +580,36 @@ class AttnSublayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kv_src, mask, h, ln_w, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo):
         _chk(x, kv_src, ln_w, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo)
-        B, nq, d = x.shape
+        packed = isinstance(mask, PackedPair)         # x [Rq, d] (and kv_src [Rk, d]) are packed rows
+        d = x.shape[-1]
         x2 = _c(x).view(-1, d)
         z, mean, rstd = ln_fwd(x2, ln_w, ln_b)
         self_attn = kv_src is None
         kv2 = z if self_attn else _c(kv_src).view(-1, d)
-        nk = nq if self_attn else kv_src.shape[1]
-        q = torch.empty(B * nq, d, device=x.device, dtype=F32)
-        k = torch.empty(B * nk, d, device=x.device, dtype=F32)
-        v = torch.empty(B * nk, d, device=x.device, dtype=F32)
+        rq, rk = x2.shape[0], kv2.shape[0]
+        q = torch.empty(rq, d, device=x.device, dtype=F32)
+        k = torch.empty(rk, d, device=x.device, dtype=F32)
+        v = torch.empty(rk, d, device=x.device, dtype=F32)
         gemm([d_fwd(z, Wq, q, bias=bq), d_fwd(kv2, Wk, k, bias=bk), d_fwd(kv2, Wv, v, bias=bv)])
-        a, lse = mha_fwd(q.view(B, nq, d), k.view(B, nk, d), v.view(B, nk, d), mask, h)
+        if packed:
+            a, lse = mha_fwd_packed(q, k, v, mask, h)
+        else:
+            B, nq = x.shape[0], x.shape[1]
+            nk = nq if self_attn else kv_src.shape[1]
+            a, lse = mha_fwd(q.view(B, nq, d), k.view(B, nk, d), v.view(B, nk, d), mask, h)
         y = torch.empty_like(x2)
         gemm([d_fwd(a.view(-1, d), Wo, y, bias=bo, residual=x2)])
         ctx.save_for_backward(x2, z, mean, rstd, kv2 if not self_attn else None, q, k, v, a, lse,
                               ln_w, Wq, Wk, Wv, Wo)
-        ctx.mask, ctx.h, ctx.self_attn, ctx.shape, ctx.nk = mask, h, self_attn, (B, nq, d), nk
+        ctx.mask, ctx.h, ctx.self_attn, ctx.packed = mask, h, self_attn, packed
+        ctx.xshape, ctx.kvshape = x.shape, (None if self_attn else kv_src.shape)
         ctx.params = live(ln_w, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo)
-        return y.view(B, nq, d)
+        return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
         x2, z, mean, rstd, kv2, q, k, v, a, lse, ln_w, Wq, Wk, Wv, Wo = ctx.saved_tensors
-        B, nq, d = ctx.shape
-        nk = ctx.nk
+        d = x2.shape[1]
         if kv2 is None:
             kv2 = z
         dy2 = _c(dy).view(-1, d)
@@ -476,7 +617,12 @@ class AttnSublayerFn(torch.autograd.Function):
         (dlnw, dlnb), _ = ln_param_buffers(ctx.params[0], ctx.params[1], ln_w)
         da = torch.empty_like(a).view(-1, d)
         gemm([d_dgrad([dy2], [Wo], da)] + wgrad_descs(dy2, a.view(-1, d), dWo, dbo))
-        dq, dk_, dv = mha_bwd(q.view(B, nq, d), k.view(B, nk, d), v.view(B, nk, d), ctx.mask, ctx.h, a, da.view(B, nq, d), lse)
+        if ctx.packed:
+            dq, dk_, dv = mha_bwd_packed(q, k, v, ctx.mask, ctx.h, da, lse)
+        else:
+            B, nq = ctx.xshape[0], ctx.xshape[1]
+            nk = nq if ctx.self_attn else ctx.kvshape[1]
+            dq, dk_, dv = mha_bwd(q.view(B, nq, d), k.view(B, nk, d), v.view(B, nk, d), ctx.mask, ctx.h, a, da.view(B, nq, d), lse)
         dq2, dk2, dv2 = dq.view(-1, d), dk_.view(-1, d), dv.view(-1, d)
         dz = torch.empty_like(z)
         descs = wgrad_descs(dq2, z, dWq, dbq) + wgrad_descs(dk2, kv2, dWk, dbk) + wgrad_descs(dv2, kv2, dWv, dbv)
@@ -491,7 +637,7 @@ class AttnSublayerFn(torch.autograd.Function):
         gemm(descs)
         dx = ln_bwd(dz, x2, ln_w, mean, rstd, dlnw, dlnb, dx_add=dy2)
         grads_written(ctx.params)
-        return (dx.view(B, nq, d), dkv.view(B, nk, d) if dkv is not None else None, None, None) + tuple(rets)
+        return (dx.view(ctx.xshape), dkv.view(ctx.kvshape) if dkv is not None else None, None, None) + tuple(rets)
 
 
 class FFNSublayerFn(torch.autograd.Function):

@@ -172,8 +172,20 @@ class Seq2seq(BaseModel):
         mask = (torch.arange(losses.shape[1], device=losses.device).unsqueeze(0) < (inp_lengths + 1).unsqueeze(1)).float()
         return (losses * mask).sum() / batch_size * self.args.length_factor
 
+    pack_rows = True            # Encoder / Decoder stacks of the training steps run on the real (unpadded) rows only
+    pack_min_tokens = 4096      # ... when the step is GPU-bound (below, the index bookkeeping costs more host time than it saves)
+
     def f_step(self, incoming, temperature, cyc_rec_enable=True, *, use_inference_z):
         """seq2seq.py:416-543 -> (slf, cyc, adv, slf_len, cyc_len, slf_gen_err, cyc_gen_err) as Python floats."""
+        with ops.packed_rows(self.pack_rows and incoming.data.sent.numel() >= self.pack_min_tokens):
+            return self._f_step(incoming, temperature, cyc_rec_enable, use_inference_z=use_inference_z)
+
+    def d_step(self, incoming, temperature, *, use_inference_z):
+        """seq2seq.py:551-642 -> adv_loss (float)"""
+        with ops.packed_rows(self.pack_rows and incoming.data.sent.numel() >= self.pack_min_tokens):
+            return self._d_step(incoming, temperature, use_inference_z=use_inference_z)
+
+    def _f_step(self, incoming, temperature, cyc_rec_enable=True, *, use_inference_z):
         self.net.model_D.eval()
         dm = self.param.volatile.dm
         pad_idx, eos_idx = dm.pad_id, dm.eos_id
@@ -186,6 +198,8 @@ class Seq2seq(BaseModel):
         rev_styles = 1 - raw_styles
         batch_size = inp_tokens.size(0)
         token_mask = (inp_tokens != pad_idx).float()
+        if ops.PACK_ROWS and inp_lengths.is_cuda:
+            ops.set_total(inp_lengths, inp_lengths.sum().item())       # read while the GPU is idle (start of the step)
 
         self.optimizer_F.zero_grad(set_to_none=False)   # gradient buffers persist: the HIP kernels accumulate in place
 
@@ -302,8 +316,7 @@ class Seq2seq(BaseModel):
         return slf_rec_loss.item(), cyc_rec_loss.item(), adv_loss.item(), \
             item(slf_rec_length_loss), item(cyc_rec_length_loss), item(slf_gen_error), item(cyc_gen_error)
 
-    def d_step(self, incoming, temperature, *, use_inference_z):
-        """seq2seq.py:551-642 -> adv_loss (float)"""
+    def _d_step(self, incoming, temperature, *, use_inference_z):
         dm = self.param.volatile.dm
         self.net.model_F.eval()
         eos_idx = dm.eos_id
@@ -315,6 +328,8 @@ class Seq2seq(BaseModel):
         rev_styles = 1 - raw_styles
         batch_size = inp_tokens.size(0)
         model_F, model_D = self.net.model_F, self.net.model_D
+        if ops.PACK_ROWS and inp_lengths.is_cuda:
+            ops.set_total(inp_lengths, inp_lengths.sum().item())
 
         # The discriminator's forward on the gold sentences needs nothing from the generator: it is issued on the second
         # stream first, so it fills the CUs that the latency-bound generation (greedy decode) leaves idle.
@@ -339,15 +354,21 @@ class Seq2seq(BaseModel):
                 # 2B sentences -- every op is per sentence, and the greedy skip decoding (latency-bound: ~800 small
                 # dependent launches) is paid once instead of twice.  Each half is then cut back to its own width
                 # (max generated length of that half), which is what the separate calls return.
+                both_inp_lengths = torch.cat((inp_lengths, inp_lengths), 0)
+                if hasattr(inp_lengths, "nast_total"):
+                    ops.set_total(both_inp_lengths, 2 * inp_lengths.nast_total)
                 both_log_probs, both_lengths, _, _, _ = model_F(
-                    torch.cat((inp_tokens, inp_tokens), 0), torch.cat((inp_lengths, inp_lengths), 0), None, None,
+                    torch.cat((inp_tokens, inp_tokens), 0), both_inp_lengths, None, None,
                     torch.cat((raw_styles, rev_styles), 0), generate=True, differentiable_decode=True,
                     temperature=temperature, use_inference_z=use_inference_z)
                 raw_gen_log_probs, rev_gen_log_probs = both_log_probs[:batch_size], both_log_probs[batch_size:]
                 raw_gen_lengths = rev_gen_lengths = None
                 if both_lengths is not None:
                     raw_gen_lengths, rev_gen_lengths = both_lengths[:batch_size], both_lengths[batch_size:]
-                    t_raw, t_rev = torch.stack((raw_gen_lengths.max(), rev_gen_lengths.max())).tolist()
+                    t_raw, t_rev, s_raw, s_rev = torch.stack((raw_gen_lengths.max(), rev_gen_lengths.max(),
+                                                              raw_gen_lengths.sum(), rev_gen_lengths.sum())).tolist()
+                    ops.set_total(raw_gen_lengths, s_raw)
+                    ops.set_total(rev_gen_lengths, s_rev)
                     raw_gen_log_probs, rev_gen_log_probs = raw_gen_log_probs[:, :t_raw], rev_gen_log_probs[:, :t_rev]
             else:
                 raw_gen_log_probs, raw_gen_lengths, _, _, _ = model_F(

@@ -82,7 +82,9 @@ def _pad_mask(lengths, width, extra):
     m = torch.arange(width, device=lengths.device).unsqueeze(0) >= lengths.unsqueeze(-1)
     if extra:
         m = torch.cat((torch.zeros(B, extra, dtype=torch.bool, device=lengths.device), m), 1)
-    return m.view(B, 1, 1, extra + width)
+    m = m.view(B, 1, 1, extra + width)
+    m.nast_lengths = (lengths, extra)          # lets Encoder / Decoder run on packed rows (ops.packed_of)
+    return m
 
 
 # ------------------------------------------------------------------------------------------------
@@ -195,6 +197,16 @@ class Encoder(nn.Module):
     def forward(self, x, mask, rows=None):
         """transformer.py:163-171.  rows=(grp, grp_stride, grp_off, rows_out): normalise only those rows."""
         assert x.size(1) == mask.size(-1)
+        ps = ops.packed_of(mask, x)
+        if ps is not None and (rows is None or (rows[0] == 1 and rows[2] == 0)):
+            # packed rows: only the real tokens of every sentence go through the layers
+            y = ops.pack_rows(x, ps)
+            pair = ops.PackedPair(ps, ps)
+            for layer in self.layers:
+                y = layer(y, pair)
+            if rows is not None:                               # first row of every sentence (the discriminator's cls row)
+                return self.norm(y.index_select(0, ps.off))
+            return ops.unpack_rows(self.norm(y), ps)
         y = x
         for layer in self.layers:
             y = layer(y, mask)
@@ -228,6 +240,9 @@ class Decoder(nn.Module):
         (what StyleTransformer keeps, transformer.py:103) without computing row 0; with nll_targets [B, n-1]
         the per-token negative log-likelihood of those tokens is returned instead of the log-probs."""
         assert x.size(1) == tgt_mask.size(-1)
+        pt, pm = ops.packed_of(tgt_mask, x), ops.packed_of(src_mask, memory)
+        if pt is not None and pm is not None and skip_first:
+            return self._forward_packed(x, memory, pt, pm, temperature, nll_targets)
         y = x
         for layer in self.layers:
             y = layer(y, memory, src_mask, tgt_mask)
@@ -239,6 +254,23 @@ class Decoder(nn.Module):
                 return self.generator.nll(z, temperature, nll_targets).view(B, n - 1)
             return self.generator(z, temperature).view(B, n - 1, -1)
         return self.generator(self.norm(y), temperature)
+
+    def _forward_packed(self, x, memory, pt, pm, temperature, nll_targets):
+        """The same stack on the real rows only (ops.PackedSeq); positions 1.. of every sentence are kept."""
+        B, n, d = x.shape
+        y, mem = ops.pack_rows(x, pt), ops.pack_rows(memory, pm)
+        self_pair, cross_pair = ops.PackedPair(pt, pt), ops.PackedPair(pt, pm)
+        for layer in self.layers:
+            y = layer(y, mem, cross_pair, self_pair)
+        rows, sub = pt.tail()                                   # packed rows of positions >= 1, their [B, n-1] layout
+        z = self.norm(y.index_select(0, rows))
+        if nll_targets is not None:
+            # generator + NLL on the real target positions only (padded ones are multiplied by a zero mask downstream)
+            assert nll_targets.shape == (B, n - 1)
+            tok = nll_targets.reshape(-1).index_select(0, sub.idx_p)
+            nll = self.generator.nll(z, temperature, tok).view(-1)[:sub.total]
+            return torch.zeros(B * (n - 1), device=x.device, dtype=nll.dtype).index_copy(0, sub.idx, nll).view(B, n - 1)
+        return self.generator(ops.unpack_rows(z, sub), temperature)
 
 
 class EmbeddingLayer(nn.Module):
@@ -301,6 +333,12 @@ class StyleTransformer(nn.Module):
         assert max_enc_len <= self.max_length
 
         src_mask = _pad_mask(inp_lengths, max_enc_len, 1)
+        if not self.args.use_learnable:
+            # Without the length predictor the decoder works on the SOURCE positions and masks by the source length
+            # (tgt_mask = src_mask, transformer.py:90) while the loss covers the gold length, and the generated length is
+            # read off the output itself (first <eos>, seq2seq.py:545-549): rows past the source length are live, so this
+            # model keeps the padded execution.  With the length predictor every consumer masks by explicit lengths.
+            del src_mask.nast_lengths
         soft_rows = self.embed.soft_rows(inp_tokens) if inp_tokens.dim() == 3 else None
         enc_input = self.embed.assemble(inp_tokens, [(self.style_embed.weight, style)], soft_rows)
         memory = self.encoder(enc_input, src_mask)
@@ -572,4 +610,7 @@ class LengthPredictor(nn.Module):
             allpos = allpos_buf[:, :steps + 1].contiguous()
         dec_input = ops.lp_gather(origin_input, origin_length, allpos, eos_embed, unk_embed, None, 0, True)   # :576-578
         target_length = (allpos < (origin_length + 1).unsqueeze(-1)).sum(dim=1) - 1                  # :580
-        return dec_input[:, :target_length.max() + 1], target_length, allpos
+        # one device-to-host read for the width (the reference's .max(), :582) and the total (packed rows downstream)
+        t_max, t_sum = torch.stack((target_length.max(), target_length.sum())).tolist()
+        ops.set_total(target_length, t_sum)
+        return dec_input[:, :t_max + 1], target_length, allpos

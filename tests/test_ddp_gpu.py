@@ -27,6 +27,7 @@ faulthandler.dump_traceback_later(60, exit=True)       # a stuck collective name
 learnable = sys.argv[2].startswith("learnable")
 if sys.argv[2].endswith("2streams"):          # the second-stream overlap that production batches (>= 4096 tokens) use
     Seq2seq.overlap_min_tokens = 0
+    Seq2seq.pack_min_tokens = 0
     # (one bucket here: several outstanding gloo collectives on CUDA tensors stall inside ProcessGroupGloo on this image;
     # many small buckets leaving while backward still runs are covered on CPU by tests/test_host_cpu.py)
 torch.cuda.set_device(0)

@@ -424,3 +424,30 @@ def test_fused_adam_matches_torch(ops, max_norm, wd):
         assert float(sd_ref["state"][k]["step"]) == float(sd_got["state"][k]["step"])
         # the clip coefficient carries the rounding of two different fp32 reductions of ~3e6 squares (norms agree to 1e-5)
         np.testing.assert_allclose(sd_got["state"][k]["exp_avg_sq"].cpu().numpy(), sd_ref["state"][k]["exp_avg_sq"].numpy(), rtol=5e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("B,nq,nk,h,dk", [(6, 33, 33, 4, 64), (5, 20, 48, 2, 32), (3, 64, 17, 4, 16), (4, 9, 9, 2, 8)])
+def test_attention_packed_rows(ops, B, nq, nk, h, dk):
+    """nast_mha_*_varlen_f32 on packed rows == the padded call with a key-padding mask, on the real rows (forward and
+    all three gradients); sentences of length 1 and of full width included."""
+    g = torch.Generator().manual_seed(11 * B + nq)
+    D = h * dk
+    ql = torch.randint(1, nq + 1, (B,), generator=g); ql[0], ql[-1] = nq, 1
+    kl = torch.randint(1, nk + 1, (B,), generator=g); kl[0], kl[-1] = nk, 1
+    q, k, v = (torch.randn(B, n, D, generator=g) for n in (nq, nk, nk))
+    R = torch.randn(B, nq, D, generator=g) * (torch.arange(nq)[None] < ql[:, None]).unsqueeze(-1)
+    mask = (torch.arange(nk)[None] >= kl[:, None]).view(B, 1, 1, nk)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    (ref_attention(qr, kr, vr, mask, h) * R).sum().backward()
+    yref = ref_attention(q, k, v, mask, h)
+    pq, pk = ops.PackedSeq(dev(ql), nq), ops.PackedSeq(dev(kl), nk)
+    pair = ops.PackedPair(pq, pk)
+    qp, kp, vp = ops.pack_rows(dev(q), pq), ops.pack_rows(dev(k), pk), ops.pack_rows(dev(v), pk)
+    out, lse = ops.mha_fwd_packed(qp, kp, vp, pair, h)
+    dq, dk_, dv = ops.mha_bwd_packed(qp, kp, vp, pair, h, ops.pack_rows(dev(R), pq), lse)
+    qmask = (torch.arange(nq)[None] < ql[:, None]).unsqueeze(-1)
+    kmask = (torch.arange(nk)[None] < kl[:, None]).unsqueeze(-1)
+    relclose(ops.unpack_rows(out, pq), yref * qmask)
+    relclose(ops.unpack_rows(dq, pq), qr.grad * qmask)
+    relclose(ops.unpack_rows(dk_, pk), kr.grad * kmask)
+    relclose(ops.unpack_rows(dv, pk), vr.grad * kmask)

@@ -223,6 +223,7 @@ def test_training_steps_golden(tag, mode, two_streams):
     U.cuda_init(0, "cuda")
     model = Seq2seq(make_param(device="cuda", **cfg_of(g)))
     model.overlap_min_tokens = 0 if two_streams else 1 << 60
+    model.pack_min_tokens = 0 if two_streams else 1 << 60       # the packed-row execution of production batches rides along
     assert not load_weights(model.net, sub(g, "w0/"))
     model.net.model_F.train(); model.net.model_D.train()
     pref = "model_D." if mode == "d_step" else "model_F."
@@ -270,6 +271,7 @@ def _oracle_vs_hip_step(cfg, B, seed=0):
     torch.manual_seed(seed); np.random.seed(seed)
     U.cuda_init(0, "cuda")
     model = Seq2seq(make_param(device="cuda", **cfg))
+    model.overlap_min_tokens = model.pack_min_tokens = 0       # the second stream and packed rows of production batches
     gen = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for n, p in model.net.named_parameters():
