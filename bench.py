@@ -239,6 +239,7 @@ def main():
                                          "dtype": "bf16 MFMA operands, fp32 accumulate/storage"}
 
     roofline = None
+    gemm_flops_per_step = None
     if not a.no_roofline:
         # second pass over the same steps with HIP-event timing armed around every launch of the dominant
         # kernel family (grouped fp32 MFMA GEMM); kept out of the pass that produces `value`.  EVERY rank runs
@@ -264,6 +265,7 @@ def main():
             # the small-M GEMM kernel of the greedy decode (M = sentences, latency-bound) and the family as a whole
             ms4, fl4, n4 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
             lib.nast_prof_get(4, ctypes.byref(ms4), ctypes.byref(fl4), ctypes.byref(n4))
+            gemm_flops_per_step = (fl.value + fl4.value) / max(min(a.steps, 5), 1)      # GEMM FLOP actually issued per step
             if ms4.value > 0:
                 roofline["decode_small_m_gemm"] = {"achieved": round(fl4.value / (ms4.value * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                                                    "launches": int(n4.value), "avg_launch_us": round(ms4.value * 1e3 / max(n4.value, 1), 2)}
@@ -310,8 +312,14 @@ def main():
                        "global_batch": B * world, "max_length": L, "parallelism": f"dp{world}"},
         }
         if key in GFLOP_PER_SENTENCE:
+            # SURVEY.md section 8d counts every sentence at the padded width.  The packed-row execution does not run the
+            # padded positions, so this is the rate the PADDED algorithm would need for the same sentences/s (it can exceed
+            # what the matrix cores executed); the executed rate is step_tflops_executed below.
             tf = sps * GFLOP_PER_SENTENCE[key] / 1e3
-            out["step_tflops"] = round(tf, 2)
+            out["step_tflops_padded_equivalent"] = round(tf, 2)
+        if gemm_flops_per_step:
+            tf = gemm_flops_per_step * world / (elapsed / a.steps) / 1e12
+            out["step_tflops_executed"] = round(tf, 2)
             out["step_frac_of_fp32_mfma_peak"] = round(tf / (PEAK_FP32_MFMA_TFLOPS * world), 4)
         if roofline:
             out["roofline"] = roofline

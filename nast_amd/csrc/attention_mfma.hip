@@ -68,6 +68,7 @@ struct AttnArgs {
   // packed ("varlen") rows: sentence b owns rows q_off[b] .. q_off[b]+q_len[b]-1 of q / out / dq and rows
   // k_off[b] .. +k_len[b]-1 of k / v / dk / dv; nq / nk are then the maxima (they size the tiles) and mask is NULL
   const int32_t *q_off, *k_off, *q_len, *k_len;
+  int causal;                                   // packed rows only: key j is visible to query i iff j <= i
 };
 
 // per-sentence geometry: padded batches use the batch strides, packed ones the offset arrays
@@ -310,8 +311,8 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
 #pragma unroll
   for (int u = 0; u < NT * 4; ++u) {
     const int row = 4 * u + wave;
-    const unsigned long long mq = __ballot(row >= nq || lane >= nk || mq_b[u] != 0);
-    const unsigned long long mk = __ballot(row >= nk || lane >= nq || mk_b[u] != 0);
+    const unsigned long long mq = __ballot(row >= nq || lane >= nk || mq_b[u] != 0 || (P.causal && lane > row));
+    const unsigned long long mk = __ballot(row >= nk || lane >= nq || mk_b[u] != 0 || (P.causal && row > lane));
     if (lane == 0) {
       dead_q[row] = mq;
       dead_k[row] = mk;
@@ -541,8 +542,13 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_wave_kernel(const AttnArgs P
             w |= (uint32_t)(j >= nk || mrow[j < nk ? j : 0] != 0) << (4 * jt + r);
           }
       } else {
+        unsigned long long dr = dead_row;
+        if (P.causal) {                            // keys after this lane's query
+          const int i = 16 * it + r15;
+          dr |= i < 63 ? (~0ull << (i + 1)) : 0ull;
+        }
 #pragma unroll
-        for (int jt = 0; jt < NKE; ++jt) w |= ((uint32_t)(dead_row >> (16 * jt + 4 * g)) & 15u) << (4 * jt);
+        for (int jt = 0; jt < NKE; ++jt) w |= ((uint32_t)(dr >> (16 * jt + 4 * g)) & 15u) << (4 * jt);
       }
       return w;
     };
@@ -677,10 +683,10 @@ int launch_bwd_nt(const AttnArgs& A, int nt, hipStream_t s) {
 int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, float* out, float* lse, int B, int h, int nq,
                       int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                       int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s, const int32_t* q_off, const int32_t* k_off,
-                      const int32_t* q_len, const int32_t* k_len) {
+                      const int32_t* q_len, const int32_t* k_len, int causal) {
   if (nq > 64 || nk > 64) return 1;
   AttnArgs A = {};
-  A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len;
+  A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len; A.causal = causal;
   A.q = q; A.k = k; A.v = v; A.mask = mask; A.out = out; A.lse = lse;
   A.BH = B * h; A.h = h; A.nq = nq; A.nk = nk; A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.ldo = ldo;
   A.q_bs = q_bs; A.k_bs = k_bs; A.v_bs = v_bs; A.o_bs = o_bs; A.mask_bs = mask_bs; A.mask_qs = mask_qs; A.scale = scale;
@@ -697,10 +703,10 @@ int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint
 int nast_mha_bwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, const float* dout, const float* lse, float* dq,
                       float* dk_, float* dv, int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs,
                       int64_t k_bs, int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s,
-                      const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len) {
+                      const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len, int causal) {
   if (nq > 64 || nk > 64) return 1;
   AttnArgs A = {};
-  A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len;
+  A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len; A.causal = causal;
   A.q = q; A.k = k; A.v = v; A.mask = mask; A.dout = dout; A.lse_in = lse; A.dq = dq; A.dk = dk_; A.dv = dv;
   A.BH = B * h; A.h = h; A.nq = nq; A.nk = nk; A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.ldo = ldo;
   A.q_bs = q_bs; A.k_bs = k_bs; A.v_bs = v_bs; A.o_bs = o_bs; A.mask_bs = mask_bs; A.mask_qs = mask_qs; A.scale = scale;

@@ -409,9 +409,20 @@ class HiddenDecoder(nn.Module):
         self.layers = nn.ModuleList([DecoderLayer(d_model, h, dropout) for _ in range(num_layers)])
         self.norm = LayerNorm(d_model)
 
-    def forward(self, x, memory, src_mask, tgt_mask):
-        """transformer.py:359-364 -- NB: no final LayerNorm here (the reference's train/inference asymmetry)."""
+    def forward(self, x, memory, src_mask, tgt_mask, causal_lengths=None):
+        """transformer.py:359-364 -- NB: no final LayerNorm here (the reference's train/inference asymmetry).
+        causal_lengths [B] (extension): tgt_mask is the plain causal mask and only the first causal_lengths[b] positions of
+        sentence b are consumed downstream -- the stack may then run on those rows only (ops.PackedSeq); the other
+        positions come back as zeros."""
         assert x.size(1) == tgt_mask.size(-1)
+        pm = ops.packed_of(src_mask, memory) if causal_lengths is not None else None
+        if pm is not None and x.size(1) <= ops.PACK_MAX_LEN:
+            pt = ops.PackedSeq(causal_lengths, x.size(1))
+            y, mem = ops.pack_rows(x, pt), ops.pack_rows(memory, pm)
+            self_pair, cross_pair = ops.PackedPair(pt, pt, causal=True), ops.PackedPair(pt, pm)
+            for layer in self.layers:
+                y = layer(y, mem, cross_pair, self_pair)
+            return ops.unpack_rows(y, pt)
         y = x
         for layer in self.layers:
             y = layer(y, memory, src_mask, tgt_mask)
@@ -582,7 +593,12 @@ class LengthPredictor(nn.Module):
             dec_input_new = ops.lp_gather(origin_input, origin_length, allpos, eos_embed, unk_embed, self.pos_embed.weight, 0, True)
             Lm = self.args.max_length + 1
             causal = (torch.ones((Lm, Lm), device=dev).tril() == 0).view(1, 1, Lm, Lm)   # :463-464
-            hidden = self.decoder(dec_input_new, memory, src_mask, causal[:, :, :T1, :T1])
+            # positions 0..target_length of a sentence are the ones its loss reads (seq2seq.py:461); a causal stack never
+            # lets a later position influence them
+            live_len = target_length + 1
+            if hasattr(target_length, "nast_total"):
+                ops.set_total(live_len, target_length.nast_total + batch_size)
+            hidden = self.decoder(dec_input_new, memory, src_mask, causal[:, :, :T1, :T1], causal_lengths=live_len)
             # skip logits (:504-507): wk is linear, so wk(candidates)[allpos+j] == wk applied once per source row
             cand_idx = torch.arange(S1 + 5, device=dev).unsqueeze(0).expand(batch_size, -1)
             cand_in = ops.lp_gather(origin_input, origin_length, cand_idx, eos_embed, unk_embed, None, 0, False)

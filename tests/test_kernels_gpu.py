@@ -451,3 +451,27 @@ def test_attention_packed_rows(ops, B, nq, nk, h, dk):
     relclose(ops.unpack_rows(dq, pq), qr.grad * qmask)
     relclose(ops.unpack_rows(dk_, pk), kr.grad * kmask)
     relclose(ops.unpack_rows(dv, pk), vr.grad * kmask)
+
+
+def test_attention_packed_rows_causal(ops):
+    """causal flag of the packed attention entry points == the padded call with the causal mask, on the real rows"""
+    B, n, h, dk = 5, 33, 4, 64
+    g = torch.Generator().manual_seed(5)
+    D = h * dk
+    ln = torch.randint(1, n + 1, (B,), generator=g); ln[0], ln[-1] = n, 1
+    q, k, v = (torch.randn(B, n, D, generator=g) for _ in range(3))
+    live = (torch.arange(n)[None] < ln[:, None]).unsqueeze(-1)
+    R = torch.randn(B, n, D, generator=g) * live
+    mask = (torch.ones(n, n).tril() == 0).view(1, 1, n, n)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    (ref_attention(qr, kr, vr, mask, h) * R).sum().backward()
+    yref = ref_attention(q, k, v, mask, h)
+    ps = ops.PackedSeq(dev(ln), n)
+    pair = ops.PackedPair(ps, ps, causal=True)
+    qp, kp, vp = (ops.pack_rows(dev(t), ps) for t in (q, k, v))
+    out, lse = ops.mha_fwd_packed(qp, kp, vp, pair, h)
+    dq, dk_, dv = ops.mha_bwd_packed(qp, kp, vp, pair, h, ops.pack_rows(dev(R), ps), lse)
+    relclose(ops.unpack_rows(out, ps), yref * live)
+    relclose(ops.unpack_rows(dq, ps), qr.grad * live)
+    relclose(ops.unpack_rows(dk_, ps), kr.grad * live)
+    relclose(ops.unpack_rows(dv, ps), vr.grad * live)
