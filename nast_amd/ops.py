@@ -491,6 +491,31 @@ class PackedPair:
         self.q, self.k, self.causal = q, k, causal
 
 
+class PackedSoft:
+    """Soft tokens [B, T, V] of a ragged batch held as packed rows: `rows` [ps.rows, V] (autograd tensor), sentence b's
+    T_b = ps.len positions at rows ps.off[b]...  Quacks like the [B, T, V] tensor for the shape queries the model makes;
+    consumers take the rows through `soft_embed` (x @ table on real rows only) and `column` (one vocabulary column)."""
+
+    def __init__(self, rows, ps):
+        self.rows, self.ps = rows, ps
+        self.shape = (ps.B, ps.width, rows.shape[-1])
+        self.device, self.is_cuda = rows.device, rows.is_cuda
+
+    def dim(self):
+        return 3
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def soft_embed(self, table):
+        """[B, T, d] = soft tokens @ table (zeros at the padded positions)"""
+        return unpack_rows(matmul_nn(self.rows, table), self.ps)
+
+    def column(self, j):
+        """[B, T] weights of vocabulary entry j (no gradient), zeros at the padded positions"""
+        return unpack_rows(self.rows.detach()[:, j:j + 1], self.ps).squeeze(-1)
+
+
 def packed_of(mask, x):
     """PackedSeq for a padding mask made by transformer._pad_mask, or None when packing does not apply."""
     if not PACK_ROWS or mask is None or not x.is_cuda:

@@ -161,6 +161,15 @@ class Seq2seq(BaseModel):
         soft = self.approx(logits, mode)
         return soft, soft.argmax(-1)
 
+    def _approx_packed(self, lp, mode):
+        """Seq2seq.approx on packed log-probs (ops.PackedSoft) -> packed soft tokens [rows, V]"""
+        if mode == "gumbel":
+            from .utils import gumbel as G
+            if G._injected:                      # parity runs inject the reference's [B, T, V] draw: pack it the same way
+                G._injected[0] = ops.pack_rows(G._injected[0], lp.ps)
+            return gumbel_soft_and_index(lp.rows)[0]
+        return self.approx(lp.rows, mode)
+
     def get_lengths(self, tokens, eos_idx):
         """seq2seq.py:545-549: first <eos> index + 1, capped at the width."""
         return ops.first_eos_length(tokens, eos_idx)
@@ -246,7 +255,12 @@ class Seq2seq(BaseModel):
         def transfer_pass():
             glp, glen, _, _, _ = model_F(
                 inp_tokens, inp_lengths, None, None, rev_styles,
-                generate=True, differentiable_decode=True, temperature=temperature, use_inference_z=use_inference_z)
+                generate=True, differentiable_decode=True, temperature=temperature, use_inference_z=use_inference_z,
+                packed_log_probs=ops.PACK_ROWS and args.use_learnable)
+            if isinstance(glp, ops.PackedSoft):
+                # the generated sentences stay packed through the Gumbel-softmax: the cycle pass and the discriminator read
+                # them through x @ table on the real rows only
+                return ops.PackedSoft(self._approx_packed(glp, args.gen_approx_mode), glp.ps), glen
             soft, idx = self._approx_with_index(glp, args.gen_approx_mode)
             if not args.use_learnable:
                 glen = self.get_lengths(idx, eos_idx)

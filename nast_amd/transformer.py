@@ -235,14 +235,14 @@ class Decoder(nn.Module):
         self.norm = LayerNorm(d_model)
         self.generator = Generator(d_model, vocab_size)
 
-    def forward(self, x, memory, src_mask, tgt_mask, temperature, skip_first=False, nll_targets=None):
+    def forward(self, x, memory, src_mask, tgt_mask, temperature, skip_first=False, nll_targets=None, packed_out=False):
         """transformer.py:180-188.  skip_first=True returns log-probs for positions 1.. only
         (what StyleTransformer keeps, transformer.py:103) without computing row 0; with nll_targets [B, n-1]
         the per-token negative log-likelihood of those tokens is returned instead of the log-probs."""
         assert x.size(1) == tgt_mask.size(-1)
         pt, pm = ops.packed_of(tgt_mask, x), ops.packed_of(src_mask, memory)
         if pt is not None and pm is not None and skip_first:
-            return self._forward_packed(x, memory, pt, pm, temperature, nll_targets)
+            return self._forward_packed(x, memory, pt, pm, temperature, nll_targets, packed_out)
         y = x
         for layer in self.layers:
             y = layer(y, memory, src_mask, tgt_mask)
@@ -255,7 +255,7 @@ class Decoder(nn.Module):
             return self.generator(z, temperature).view(B, n - 1, -1)
         return self.generator(self.norm(y), temperature)
 
-    def _forward_packed(self, x, memory, pt, pm, temperature, nll_targets):
+    def _forward_packed(self, x, memory, pt, pm, temperature, nll_targets, packed_out=False):
         """The same stack on the real rows only (ops.PackedSeq); positions 1.. of every sentence are kept."""
         B, n, d = x.shape
         y, mem = ops.pack_rows(x, pt), ops.pack_rows(memory, pm)
@@ -270,6 +270,8 @@ class Decoder(nn.Module):
             tok = nll_targets.reshape(-1).index_select(0, sub.idx_p)
             nll = self.generator.nll(z, temperature, tok).view(-1)[:sub.total]
             return torch.zeros(B * (n - 1), device=x.device, dtype=nll.dtype).index_copy(0, sub.idx, nll).view(B, n - 1)
+        if packed_out:                                          # log-probs of the real positions only: [sub.rows, V]
+            return ops.PackedSoft(self.generator(z, temperature), sub)
         return self.generator(ops.unpack_rows(z, sub), temperature)
 
 
@@ -284,6 +286,8 @@ class EmbeddingLayer(nn.Module):
 
     def soft_rows(self, x):
         """[B,L,V] soft tokens -> [B,L,d] = x @ token_embed.weight (transformer.py:229), MFMA GEMM."""
+        if isinstance(x, ops.PackedSoft):
+            return x.soft_embed(self.token_embed.weight)
         return ops.matmul_nn(x, self.token_embed.weight)
 
     def forward(self, x, pos):
@@ -322,7 +326,8 @@ class StyleTransformer(nn.Module):
             self.length_predictor = LengthPredictor(param)
 
     def forward(self, inp_tokens, inp_lengths, gold_tokens, gold_lengths, style,
-                generate=False, differentiable_decode=False, temperature=1.0, *, use_inference_z, nll_targets=None):
+                generate=False, differentiable_decode=False, temperature=1.0, *, use_inference_z, nll_targets=None,
+                packed_log_probs=False):
         """transformer.py:48-103 -> (log_probs[:,1:], tgt_lengths, length_loss, gen_error, allpos).
         Extension: nll_targets [B,T] int64 -> the first result is -log_probs[:,1:].gather(-1, nll_targets) [B,T]
         (what seq2seq.py:453 / :504 compute from the log-probs), without materialising their gradient."""
@@ -366,8 +371,10 @@ class StyleTransformer(nn.Module):
             tgt_mask = src_mask
             tgt_lengths = length_loss = gen_error = allpos = None
 
+        # packed_log_probs (extension): when the decoder runs on packed rows, hand the log-probs back as ops.PackedSoft
+        # (real positions only) instead of the padded [B, T, V] tensor
         log_probs = self.decoder(dec_input_emb, memory, src_mask, tgt_mask, temperature, skip_first=True,
-                                 nll_targets=nll_targets)
+                                 nll_targets=nll_targets, packed_out=packed_log_probs)
         return log_probs, tgt_lengths, length_loss, gen_error, allpos
 
 
@@ -524,8 +531,13 @@ class LengthPredictor(nn.Module):
             else:
                 # soft source: (p with p[unk] folded into p[0]) @ E == p @ E + p[unk] * (E[0] - E[unk]);
                 # p @ E is the embedding GEMM the encoder input already needed (re-used when given)
-                rows = origin_soft_rows.detach() if origin_soft_rows is not None else ops.matmul_nn(origin_token.detach(), E)
-                cost0, cost = ops.align_costs(E, target_token, src_emb=rows, src_unk_w=origin_token.detach()[..., unk_id],
+                packed = isinstance(origin_token, ops.PackedSoft)
+                if origin_soft_rows is not None:
+                    rows = origin_soft_rows.detach()
+                else:
+                    rows = origin_token.soft_embed(E).detach() if packed else ops.matmul_nn(origin_token.detach(), E)
+                unk_w = origin_token.column(unk_id) if packed else origin_token.detach()[..., unk_id]
+                cost0, cost = ops.align_costs(E, target_token, src_emb=rows, src_unk_w=unk_w,
                                               unk_id=unk_id)
             return ops.align_viterbi(cost0, cost, origin_length, target_length)
 
