@@ -240,3 +240,32 @@ def test_grad_reducer_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_packed_seq_index_maps():
+    """ops.PackedSeq: packed <-> padded row maps, the multiple-of-64 padding, tail() (positions >= 1) and host totals."""
+    import torch
+    from nast_amd import ops
+    lengths = torch.tensor([3, 1, 5, 2])
+    n, d = 5, 4
+    ps = ops.PackedSeq(ops.set_total(lengths.clone(), 11), n)
+    assert ps.total == 11 and ps.rows == 64 and ps.idx.tolist() == [0, 1, 2, 5, 10, 11, 12, 13, 14, 15, 16]
+    assert ps.off32.tolist() == [0, 3, 4, 9] and ps.len32.tolist() == [3, 1, 5, 2]
+    assert ps.idx_p.shape[0] == 64 and ps.idx_p[11:].abs().sum() == 0           # padding rows copy row 0
+    x = torch.arange(4 * n * d, dtype=torch.float32).view(4, n, d).requires_grad_(True)
+    xp = ops.pack_rows(x, ps)
+    assert xp.shape == (64, d) and torch.equal(xp[:11], x.view(-1, d)[ps.idx])
+    back = ops.unpack_rows(xp, ps)
+    live = (torch.arange(n)[None] < lengths[:, None]).unsqueeze(-1)
+    assert torch.equal(back, x.detach() * live)
+    back.sum().backward()                                                        # only real rows receive gradient
+    assert torch.equal(x.grad, live.expand_as(x).float())
+    rows, sub = ps.tail()
+    assert sub.total == 7 and sub.width == n - 1 and sub.len32.tolist() == [2, 0, 4, 1]
+    assert rows[:7].tolist() == [1, 2, 5, 6, 7, 8, 10] and sub.idx.tolist() == [0, 1, 8, 9, 10, 11, 12]
+    # without a host total the constructor reads it from the device tensor
+    assert ops.PackedSeq(lengths, n).total == 11
+    # PackedSoft answers the shape queries of a [B, T, V] tensor
+    soft = ops.PackedSoft(torch.zeros(ps.rows, 7), ps)
+    assert soft.dim() == 3 and soft.size(0) == 4 and soft.size(1) == n and soft.shape == (4, n, 7)
+    assert soft.column(3).shape == (4, n)

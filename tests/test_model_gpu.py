@@ -17,7 +17,7 @@ def T(a):
 
 def relclose(a, b, tol=1e-4, what=""):
     a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (what, a.shape, b.shape)
     err = np.abs(a - b).max() if a.size else 0.0
     scale = np.abs(b).max() + 1e-30
@@ -149,6 +149,70 @@ def test_style_transformer_golden(tag):
             relclose(torch.cat(ys, 1), g["out/hd/incremental"], what="hd.incremental")
             cache = tf.KVCacheDecoder(hd, mem, sm, n)
             relclose(torch.stack([cache.step(x[:, k].contiguous(), k) for k in range(n)], 1), g["out/hd/incremental"], what="kv-cache")
+
+
+def test_style_transformer_packed_rows_golden():
+    """Packed-row execution (ops.packed_rows) of the learnable StyleTransformer against the reference's golden vectors:
+    log-probs at the real target positions, per-token NLL, the length losses and every parameter gradient -- with hard and
+    with soft (packed: ops.PackedSoft) source tokens.  Cotangents are zero at padded positions, as in the training step."""
+    from nast_amd import ops
+    from nast_amd import transformer as tf
+    g = load_golden("g2_style_transformer_learnable")
+    F = tf.StyleTransformer(make_param(**cfg_of(g))).to(DEV)
+    assert not load_weights(F, sub(g, "w/"))
+    src, sl, gold, gl, style = (T(g[k]) for k in ("in/src", "in/src_len", "in/gold", "in/gold_len", "in/style"))
+    live = (torch.arange(gold.shape[1], device=DEV)[None] < gl[:, None])
+    ref_lp = T(g["out/teacher_hard/log_probs"])
+
+    with ops.packed_rows(True):
+        # log-probs at the real positions
+        with torch.no_grad():
+            lp = F(src, sl, gold, gl, style, generate=False, temperature=1.0, use_inference_z=True)[0]
+        relclose(lp * live.unsqueeze(-1), ref_lp * live.unsqueeze(-1), what="packed log_probs")
+        # NLL + length loss and their gradients == the padded golden run with cotangents masked to the real positions
+        Rm = T(g["in/teacher_hard/R"]) * live.unsqueeze(-1)
+        F.zero_grad()
+        ref = tf.StyleTransformer(make_param(**cfg_of(g))).to(DEV)
+        load_weights(ref, sub(g, "w/"))
+        Wl = T(g["in/teacher_hard/W"]) * (torch.arange(gold.shape[1] + 1, device=DEV)[None] <= gl[:, None])
+    # reference gradients: padded execution (pinned by test_style_transformer_golden) with the same masked cotangents
+    lp_r, _, ll_r, _, _ = ref(src, sl, gold, gl, style, generate=False, temperature=1.0, use_inference_z=True)
+    ((lp_r * Rm).sum() + (ll_r * Wl).sum()).backward()
+    with ops.packed_rows(True):
+        lp_p, _, ll_p, _, _ = F(src, sl, gold, gl, style, generate=False, temperature=1.0, use_inference_z=True)
+        ((lp_p * Rm).sum() + (ll_p * Wl).sum()).backward()
+    relclose(ll_p * (Wl != 0), ll_r * (Wl != 0), what="packed length_loss")
+    _same_grads(F, ref)
+
+    # soft source tokens: padded tensor vs the same rows handed over packed
+    soft = T(g["in/teacher_soft/soft"])
+    tok = gold                                   # nll targets
+    F.zero_grad(); ref.zero_grad()
+    s_ref = soft.clone().requires_grad_(True)
+    nll_r = ref(s_ref, sl, gold, gl, style, generate=False, temperature=1.0, use_inference_z=True, nll_targets=tok)[0]
+    (nll_r * live).sum().backward()
+    with ops.packed_rows(True):
+        ps = ops.PackedSeq(sl, soft.shape[1])
+        rows = ops.pack_rows(soft, ps).requires_grad_(True)
+        nll_p = F(ops.PackedSoft(rows, ps), sl, gold, gl, style, generate=False, temperature=1.0, use_inference_z=True,
+                  nll_targets=tok)[0]
+        (nll_p * live).sum().backward()
+    relclose(nll_p * live, nll_r * live, what="packed nll (soft source)")
+    src_live = (torch.arange(soft.shape[1], device=DEV)[None] < sl[:, None]).unsqueeze(-1)
+    relclose(ops.unpack_rows(rows.grad, ps), s_ref.grad * src_live, 2e-4, what="grad wrt soft tokens")
+    _same_grads(F, ref)
+
+
+def _same_grads(model, ref, tol=2e-4):
+    """Gradients of two models agree, relative to the largest gradient of the model (key biases have analytically zero
+    gradients -- softmax is shift invariant -- whose rounding noise has no scale of its own)."""
+    pairs = [(n, p.grad, q.grad) for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters())]
+    gscale = max(float(q.abs().max()) for _, _, q in pairs if q is not None)
+    for n, p, q in pairs:
+        if q is None:
+            assert p is None or float(p.abs().max()) == 0, n
+        else:
+            assert float((p - q).abs().max()) <= tol * gscale, (n, float((p - q).abs().max()), gscale)
 
 
 @pytest.mark.parametrize("disc", ["cond", "multi"])
