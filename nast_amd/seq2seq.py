@@ -161,12 +161,24 @@ class Seq2seq(BaseModel):
         soft = self.approx(logits, mode)
         return soft, soft.argmax(-1)
 
-    def _approx_packed(self, lp, mode):
-        """Seq2seq.approx on packed log-probs (ops.PackedSoft) -> packed soft tokens [rows, V]"""
+    def _approx_packed(self, lp, mode, halves=None):
+        """Seq2seq.approx on packed log-probs (ops.PackedSoft) -> packed soft tokens [rows, V].  halves=B: the batch is
+        two B-sentence calls of the reference run as one (d_step)."""
         if mode == "gumbel":
             from .utils import gumbel as G
-            if G._injected:                      # parity runs inject the reference's [B, T, V] draw: pack it the same way
-                G._injected[0] = ops.pack_rows(G._injected[0], lp.ps)
+            if G._injected:                      # parity runs inject the reference's [B, T, V] draws: pack them the same way
+                ps = lp.ps
+                if halves is None:
+                    G._injected[0] = ops.pack_rows(G._injected[0], ps)
+                else:                            # two draws [B, t_raw, V], [B, t_rev, V], each at its own width
+                    e0, e1 = G._injected.pop(0), G._injected.pop(0)
+                    first = ps.b_of < halves
+                    i0 = (ps.b_of * e0.shape[1] + ps.pos).clamp(max=e0.shape[0] * e0.shape[1] - 1)
+                    i1 = ((ps.b_of - halves) * e1.shape[1] + ps.pos).clamp(min=0)
+                    rows = torch.where(first.unsqueeze(-1), e0.reshape(-1, e0.shape[-1]).index_select(0, i0),
+                                       e1.reshape(-1, e1.shape[-1]).index_select(0, i1))
+                    pad = rows.new_ones(ps.rows - ps.total, rows.shape[-1])
+                    G._injected.insert(0, torch.cat((rows, pad), 0))
             return gumbel_soft_and_index(lp.rows)[0]
         return self.approx(lp.rows, mode)
 
@@ -362,6 +374,7 @@ class Seq2seq(BaseModel):
             with torch.cuda.stream(side):
                 gold_log_probs, gold_labels = gold_forward()
 
+        both_packed = None
         with torch.no_grad():
             if inp_tokens.is_cuda and 2 * batch_size <= self.merge_generate_max:
                 # The two generation passes (seq2seq.py:565-580) differ only in the style token: they run as ONE batch of
@@ -374,10 +387,14 @@ class Seq2seq(BaseModel):
                 both_log_probs, both_lengths, _, _, _ = model_F(
                     torch.cat((inp_tokens, inp_tokens), 0), both_inp_lengths, None, None,
                     torch.cat((raw_styles, rev_styles), 0), generate=True, differentiable_decode=True,
-                    temperature=temperature, use_inference_z=use_inference_z)
-                raw_gen_log_probs, rev_gen_log_probs = both_log_probs[:batch_size], both_log_probs[batch_size:]
+                    temperature=temperature, use_inference_z=use_inference_z,
+                    packed_log_probs=ops.PACK_ROWS and args.use_learnable)
                 raw_gen_lengths = rev_gen_lengths = None
-                if both_lengths is not None:
+                if isinstance(both_log_probs, ops.PackedSoft):
+                    both_packed = both_log_probs             # real positions only; handled as one 2B batch below
+                else:
+                    raw_gen_log_probs, rev_gen_log_probs = both_log_probs[:batch_size], both_log_probs[batch_size:]
+                if both_lengths is not None and both_packed is None:
                     raw_gen_lengths, rev_gen_lengths = both_lengths[:batch_size], both_lengths[batch_size:]
                     t_raw, t_rev, s_raw, s_rev = torch.stack((raw_gen_lengths.max(), rev_gen_lengths.max(),
                                                               raw_gen_lengths.sum(), rev_gen_lengths.sum())).tolist()
@@ -392,16 +409,27 @@ class Seq2seq(BaseModel):
                     inp_tokens, inp_lengths, None, None, rev_styles, generate=True, differentiable_decode=True,
                     temperature=temperature, use_inference_z=use_inference_z)
 
-        raw_gen_soft_tokens, raw_idx = self._approx_with_index(raw_gen_log_probs, args.dis_approx_mode)
-        if not args.use_learnable:
-            raw_gen_lengths = self.get_lengths(raw_idx, eos_idx)
-        rev_gen_soft_tokens, rev_idx = self._approx_with_index(rev_gen_log_probs, args.dis_approx_mode)
-        if not args.use_learnable:
-            rev_gen_lengths = self.get_lengths(rev_idx, eos_idx)
+        if both_packed is None:
+            raw_gen_soft_tokens, raw_idx = self._approx_with_index(raw_gen_log_probs, args.dis_approx_mode)
+            if not args.use_learnable:
+                raw_gen_lengths = self.get_lengths(raw_idx, eos_idx)
+            rev_gen_soft_tokens, rev_idx = self._approx_with_index(rev_gen_log_probs, args.dis_approx_mode)
+            if not args.use_learnable:
+                rev_gen_lengths = self.get_lengths(rev_idx, eos_idx)
 
         if not overlap:
             gold_log_probs, gold_labels = gold_forward()
-        if args.discriminator_method == 'Multi':
+        if both_packed is not None:
+            # packed rows: Gumbel-softmax and the discriminator see the 2B generated sentences as one batch, raw styles first --
+            # the row order of torch.cat((D(raw ...), D(rev ...)), 0) in seq2seq.py:601-616
+            both_soft = ops.PackedSoft(self._approx_packed(both_packed, args.dis_approx_mode, halves=batch_size), both_packed.ps)
+            if args.discriminator_method == 'Multi':
+                gen_log_probs = model_D(both_soft, both_lengths)
+                gen_labels = torch.cat((raw_styles + 1, torch.zeros_like(rev_styles)), 0)
+            else:
+                gen_log_probs = model_D(both_soft, both_lengths, torch.cat((raw_styles, rev_styles), 0))
+                gen_labels = torch.cat((torch.ones_like(raw_styles), torch.zeros_like(rev_styles)), 0)
+        elif args.discriminator_method == 'Multi':
             gen_log_probs = torch.cat((model_D(raw_gen_soft_tokens, raw_gen_lengths),
                                        model_D(rev_gen_soft_tokens, rev_gen_lengths)), 0)
             gen_labels = torch.cat((raw_styles + 1, torch.zeros_like(rev_styles)), 0)
