@@ -228,12 +228,11 @@ class Seq2seq(BaseModel):
         noise_inp_tokens = noise_inp_tokens.transpose(0, 1).contiguous()
 
         model_F = self.net.model_F
-        # The transfer pass (seq2seq.py:476-490) depends on nothing the self-reconstruction pass produces, and a large
-        # part of it is the greedy skip decoding: ~800 small dependent launches that leave most of the 256 CUs idle.
-        # It is therefore issued on a second HIP stream AFTER the whole first pass (forward + backward #1) has been
-        # enqueued on the main stream, so the GPU runs both at once; the streams join before the cycle pass.
-        # (small batches are bound by host launch rate, where a second stream only adds synchronisation: measured
-        # 33 -> 37 ms at 64 sentences, 69 -> 67 ms at 512)
+        # The transfer pass (seq2seq.py:476-490), the cycle pass forward and the discriminator forward depend on nothing the
+        # self-reconstruction pass produces (backward #1 only adds to .grad).  They are issued on a second HIP stream after
+        # the whole first pass (forward + backward #1) has been enqueued on the main stream; the streams are ordered both
+        # ways before backward #2 and joined after it.  (Small batches are bound by the host launch rate, where a second
+        # stream only adds synchronisation: measured 33 -> 37 ms at 64 sentences.)
         overlap = self.overlap_passes and cyc_rec_enable and inp_tokens.is_cuda and inp_tokens.numel() >= self.overlap_min_tokens
         if overlap:
             main = torch.cuda.current_stream()
