@@ -630,7 +630,10 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
     const nast_gemm_desc& D = descs[i];
     nkt_of[i] = ((D.K + BK - 1) / BK) * D.nsrc;
     const bool plain = D.relu_src == nullptr && !(D.flags & NAST_GEMM_RELU) && D.nsrc == 1;
-    can_split[i] = plain && ((D.flags & NAST_GEMM_ATOMIC) || (!(D.flags & NAST_GEMM_ACCUM) && nkt_of[i] >= 4 * MIN_KT));
+    static const int plain_min = [] { const char* e = getenv("NAST_GEMM_PLAIN_SPLIT_MIN"); return e ? atoi(e) : 8; }();   // tuning aid
+    // (a plain output is cut only from K = 2048 up: the cut costs a zero-fill and atomic stores; at K = 1024 and ~620 tiles
+    // (packed rows) the uncut launch measured 70 us against 79 us)
+    can_split[i] = plain && ((D.flags & NAST_GEMM_ATOMIC) || (!(D.flags & NAST_GEMM_ACCUM) && nkt_of[i] >= plain_min * MIN_KT));
     work += (long long)P.tiles_m[i] * P.tiles_n[i] * nkt_of[i];
     if (!can_split[i] && nkt_of[i] > max_unsplit) max_unsplit = nkt_of[i];
   }
