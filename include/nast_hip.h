@@ -116,12 +116,14 @@ int nast_mha_fwd_varlen_f32(const float* q, const float* k, const float* v, floa
                             int max_nq, int max_nk, int dk, int ldq, int ldk, int ldv, int ldo,
                             const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len,
                             int causal /* != 0: key j is visible to queries i >= j only (transformer.py:463-464) */,
+                            int q_total, int q_alloc, int k_total, int k_alloc /* rows [total, alloc) of the outputs are
+                            buffer padding: written as zeros (alloc == total: none) */,
                             float scale, void* stream);
 int nast_mha_bwd_varlen_f32(const float* q, const float* k, const float* v, const float* dout, const float* lse,
                             float* dq, float* dk, float* dv, int B, int h, int max_nq, int max_nk, int dk_head,
                             int ldq, int ldk, int ldv, int ldo,
                             const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len,
-                            int causal, float scale, void* stream);
+                            int causal, int q_total, int q_alloc, int k_total, int k_alloc, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row kernels over the vocabulary axis (HBM-bound): one workgroup per row.

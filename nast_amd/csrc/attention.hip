@@ -232,12 +232,13 @@ static int check_common(const char* name, int B, int h, int nq, int nk, int dk, 
 int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, float* out, float* lse, int B, int h, int nq,
                       int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                       int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s, const int32_t* q_off = nullptr,
-                      const int32_t* k_off = nullptr, const int32_t* q_len = nullptr, const int32_t* k_len = nullptr, int causal = 0);
+                      const int32_t* k_off = nullptr, const int32_t* q_len = nullptr, const int32_t* k_len = nullptr, int causal = 0,
+                      int q_total = 0, int q_alloc = 0, int k_total = 0, int k_alloc = 0);
 int nast_mha_bwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, const float* dout, const float* lse, float* dq,
                       float* dk_, float* dv, int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs,
                       int64_t k_bs, int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s,
                       const int32_t* q_off = nullptr, const int32_t* k_off = nullptr, const int32_t* q_len = nullptr,
-                      const int32_t* k_len = nullptr, int causal = 0);
+                      const int32_t* k_len = nullptr, int causal = 0, int q_total = 0, int q_alloc = 0, int k_total = 0, int k_alloc = 0);
 
 template <int DK>
 static int launch_fwd(const float* q, const float* k, const float* v, const uint8_t* mask, float* out, float* lse, int B,
@@ -333,16 +334,17 @@ extern "C" int nast_mha_bwd_f32(const float* q, const float* k, const float* v, 
 // that a [B, n, d] batch carries and masks simply does not exist.  max_nq / max_nk bound the lengths (<= 64).
 extern "C" int nast_mha_fwd_varlen_f32(const float* q, const float* k, const float* v, float* out, float* lse, int B, int h, int max_nq,
                                        int max_nk, int dk, int ldq, int ldk, int ldv, int ldo, const int32_t* q_off,
-                                       const int32_t* k_off, const int32_t* q_len, const int32_t* k_len, int causal, float scale,
-                                       void* stream) {
+                                       const int32_t* k_off, const int32_t* q_len, const int32_t* k_len, int causal, int q_total,
+                                       int q_alloc, int k_total, int k_alloc, float scale, void* stream) {
   int rc = check_common("nast_mha_fwd_varlen_f32", B, h, max_nq, max_nk, dk, ldq, ldk, ldv, ldo);
   if (rc) return rc;
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(q && k && v && out && lse && q_off && k_off && q_len && k_len, "nast_mha_fwd_varlen_f32: NULL pointer");
   NAST_REQUIRE(max_nq <= 64 && max_nk <= 64, "nast_mha_fwd_varlen_f32: lengths up to 64 (got %d, %d)", max_nq, max_nk);
+  NAST_REQUIRE(q_total >= 0 && q_alloc >= q_total && k_total >= 0 && k_alloc >= k_total, "nast_mha_fwd_varlen_f32: row counts");
   NAST_REQUIRE(((ldq | ldk | ldv | ldo) & 3) == 0, "nast_mha_fwd_varlen_f32: row pitches must be multiples of 4");
   rc = nast_mha_fwd_mfma(q, k, v, nullptr, out, lse, B, h, max_nq, max_nk, dk, ldq, ldk, ldv, ldo, 0, 0, 0, 0, 0, 0, scale,
-                         (hipStream_t)stream, q_off, k_off, q_len, k_len, causal);
+                         (hipStream_t)stream, q_off, k_off, q_len, k_len, causal, q_total, q_alloc, k_total, k_alloc);
   NAST_REQUIRE(rc == 0, "nast_mha_fwd_varlen_f32: head size %d not supported", dk);
   NAST_CHECK_LAUNCH("nast_mha_fwd_varlen_f32");
   return NAST_OK;
@@ -351,15 +353,17 @@ extern "C" int nast_mha_fwd_varlen_f32(const float* q, const float* k, const flo
 extern "C" int nast_mha_bwd_varlen_f32(const float* q, const float* k, const float* v, const float* dout, const float* lse, float* dq,
                                        float* dk_, float* dv, int B, int h, int max_nq, int max_nk, int dk, int ldq, int ldk, int ldv,
                                        int ldo, const int32_t* q_off, const int32_t* k_off, const int32_t* q_len,
-                                       const int32_t* k_len, int causal, float scale, void* stream) {
+                                       const int32_t* k_len, int causal, int q_total, int q_alloc, int k_total, int k_alloc,
+                                       float scale, void* stream) {
   int rc = check_common("nast_mha_bwd_varlen_f32", B, h, max_nq, max_nk, dk, ldq, ldk, ldv, ldo);
   if (rc) return rc;
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(q && k && v && dout && lse && dq && dk_ && dv && q_off && k_off && q_len && k_len, "nast_mha_bwd_varlen_f32: NULL pointer");
   NAST_REQUIRE(max_nq <= 64 && max_nk <= 64, "nast_mha_bwd_varlen_f32: lengths up to 64 (got %d, %d)", max_nq, max_nk);
+  NAST_REQUIRE(q_total >= 0 && q_alloc >= q_total && k_total >= 0 && k_alloc >= k_total, "nast_mha_bwd_varlen_f32: row counts");
   NAST_REQUIRE(((ldq | ldk | ldv | ldo) & 3) == 0, "nast_mha_bwd_varlen_f32: row pitches must be multiples of 4");
   rc = nast_mha_bwd_mfma(q, k, v, nullptr, dout, lse, dq, dk_, dv, B, h, max_nq, max_nk, dk, ldq, ldk, ldv, ldo, 0, 0, 0, 0, 0, 0, scale,
-                         (hipStream_t)stream, q_off, k_off, q_len, k_len, causal);
+                         (hipStream_t)stream, q_off, k_off, q_len, k_len, causal, q_total, q_alloc, k_total, k_alloc);
   NAST_REQUIRE(rc == 0, "nast_mha_bwd_varlen_f32: head size %d not supported", dk);
   NAST_CHECK_LAUNCH("nast_mha_bwd_varlen_f32");
   return NAST_OK;

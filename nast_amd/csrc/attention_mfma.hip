@@ -69,7 +69,16 @@ struct AttnArgs {
   // k_off[b] .. +k_len[b]-1 of k / v / dk / dv; nq / nk are then the maxima (they size the tiles) and mask is NULL
   const int32_t *q_off, *k_off, *q_len, *k_len;
   int causal;                                   // packed rows only: key j is visible to query i iff j <= i
+  // packed rows only: rows [q_total, q_alloc) of out / dq and [k_total, k_alloc) of dk / dv belong to no sentence (buffer
+  // padding); the kernels write zeros there so that the caller needs no separate fill
+  int q_total, q_alloc, k_total, k_alloc;
 };
+
+template <int DK>
+__device__ __forceinline__ void zero_pad_rows(float* __restrict__ base, int ld, int head, int row0, int row1, int tid, int nthreads) {
+  const int n = (row1 - row0) * DK;
+  for (int c = tid; c < n; c += nthreads) base[(int64_t)(row0 + c / DK) * ld + head * DK + c % DK] = 0.f;
+}
 
 // per-sentence geometry: padded batches use the batch strides, packed ones the offset arrays
 struct SeqGeom {
@@ -251,6 +260,11 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
   const int b = bh / P.h, head = bh % P.h;
   const SeqGeom G = seq_geom(P, b);
   const int nq = G.nq, nk = G.nk;
+  if (b == 0 && P.q_off != nullptr) {
+    zero_pad_rows<DK>(P.dq, P.ldq, head, P.q_total, P.q_alloc, threadIdx.x, 256);
+    zero_pad_rows<DK>(P.dk, P.ldk, head, P.k_total, P.k_alloc, threadIdx.x, 256);
+    zero_pad_rows<DK>(P.dv, P.ldv, head, P.k_total, P.k_alloc, threadIdx.x, 256);
+  }
   if (nq <= 0 || nk <= 0) return;               // (uniform for the workgroup)
   float* dQb = P.dq + G.q0 + head * DK;
   float* dKb = P.dk + G.k0 + head * DK;
@@ -508,6 +522,7 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_wave_kernel(const AttnArgs P
   const int b = bh / P.h, head = bh % P.h;
   const SeqGeom G = seq_geom(P, b);
   const int nq = G.nq, nk = G.nk;
+  if (b == 0 && P.q_off != nullptr) zero_pad_rows<DK>(P.out, P.ldo, head, P.q_total, P.q_alloc, lane, 64);
   if (nq <= 0 || nk <= 0) return;               // (uniform for the wavefront)
   const float* Kb = P.k + G.k0 + head * DK;
   const float* Vb = P.v + G.v0 + head * DK;
@@ -683,10 +698,11 @@ int launch_bwd_nt(const AttnArgs& A, int nt, hipStream_t s) {
 int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, float* out, float* lse, int B, int h, int nq,
                       int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                       int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s, const int32_t* q_off, const int32_t* k_off,
-                      const int32_t* q_len, const int32_t* k_len, int causal) {
+                      const int32_t* q_len, const int32_t* k_len, int causal, int q_total, int q_alloc, int k_total, int k_alloc) {
   if (nq > 64 || nk > 64) return 1;
   AttnArgs A = {};
   A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len; A.causal = causal;
+  A.q_total = q_total; A.q_alloc = q_alloc; A.k_total = k_total; A.k_alloc = k_alloc;
   A.q = q; A.k = k; A.v = v; A.mask = mask; A.out = out; A.lse = lse;
   A.BH = B * h; A.h = h; A.nq = nq; A.nk = nk; A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.ldo = ldo;
   A.q_bs = q_bs; A.k_bs = k_bs; A.v_bs = v_bs; A.o_bs = o_bs; A.mask_bs = mask_bs; A.mask_qs = mask_qs; A.scale = scale;
@@ -703,10 +719,11 @@ int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint
 int nast_mha_bwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, const float* dout, const float* lse, float* dq,
                       float* dk_, float* dv, int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs,
                       int64_t k_bs, int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s,
-                      const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len, int causal) {
+                      const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len, int causal, int q_total, int q_alloc, int k_total, int k_alloc) {
   if (nq > 64 || nk > 64) return 1;
   AttnArgs A = {};
   A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len; A.causal = causal;
+  A.q_total = q_total; A.q_alloc = q_alloc; A.k_total = k_total; A.k_alloc = k_alloc;
   A.q = q; A.k = k; A.v = v; A.mask = mask; A.dout = dout; A.lse_in = lse; A.dq = dq; A.dk = dk_; A.dv = dv;
   A.BH = B * h; A.h = h; A.nq = nq; A.nk = nk; A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.ldo = ldo;
   A.q_bs = q_bs; A.k_bs = k_bs; A.v_bs = v_bs; A.o_bs = o_bs; A.mask_bs = mask_bs; A.mask_qs = mask_qs; A.scale = scale;

@@ -552,10 +552,9 @@ def mha_fwd_packed(q, k, v, pair, h):
     out = torch.empty_like(q)
     lse = torch.empty(B, h, pair.q.width, device=q.device, dtype=F32)
     call("nast_mha_fwd_varlen_f32", _p(q), _p(k), _p(v), _p(out), _p(lse), B, h, pair.q.width, pair.k.width, dk, D, D, D, D,
-         _p(pair.q.off32), _p(pair.k.off32), _p(pair.q.len32), _p(pair.k.len32), int(pair.causal), 1.0 / math.sqrt(dk), _stream())
-    if out.shape[0] > pair.q.total:
-        out[pair.q.total:].zero_()                 # padding rows belong to no sentence: keep them finite
-    return out, lse
+         _p(pair.q.off32), _p(pair.k.off32), _p(pair.q.len32), _p(pair.k.len32), int(pair.causal),
+         pair.q.total, q.shape[0], pair.k.total, k.shape[0], 1.0 / math.sqrt(dk), _stream())
+    return out, lse                                # (padding rows, which belong to no sentence, come back as zeros)
 
 
 def mha_bwd_packed(q, k, v, pair, h, dout, lse):
@@ -564,11 +563,8 @@ def mha_bwd_packed(q, k, v, pair, h, dout, lse):
     dq, dk_, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     call("nast_mha_bwd_varlen_f32", _p(q), _p(k), _p(v), _p(dout), _p(lse), _p(dq), _p(dk_), _p(dv), pair.q.B, h, pair.q.width,
          pair.k.width, dk, D, D, D, D, _p(pair.q.off32), _p(pair.k.off32), _p(pair.q.len32), _p(pair.k.len32),
-         int(pair.causal), 1.0 / math.sqrt(dk), _stream())
-    for t, ps in ((dq, pair.q), (dk_, pair.k), (dv, pair.k)):
-        if t.shape[0] > ps.total:
-            t[ps.total:].zero_()                   # ... and their gradient exactly zero
-    return dq, dk_, dv
+         int(pair.causal), pair.q.total, q.shape[0], pair.k.total, k.shape[0], 1.0 / math.sqrt(dk), _stream())
+    return dq, dk_, dv                             # (padding rows get exactly zero gradient, written by the kernel)
 
 
 class AttentionFn(torch.autograd.Function):

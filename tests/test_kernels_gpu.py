@@ -447,6 +447,8 @@ def test_attention_packed_rows(ops, B, nq, nk, h, dk):
     dq, dk_, dv = ops.mha_bwd_packed(qp, kp, vp, pair, h, ops.pack_rows(dev(R), pq), lse)
     qmask = (torch.arange(nq)[None] < ql[:, None]).unsqueeze(-1)
     kmask = (torch.arange(nk)[None] < kl[:, None]).unsqueeze(-1)
+    for t, ps_ in ((out, pq), (dq, pq), (dk_, pk), (dv, pk)):         # buffer padding rows come back as exact zeros
+        assert t.shape[0] == ps_.rows and float(t[ps_.total:].abs().max()) == 0.0
     relclose(ops.unpack_rows(out, pq), yref * qmask)
     relclose(ops.unpack_rows(dq, pq), qr.grad * qmask)
     relclose(ops.unpack_rows(dk_, pk), kr.grad * kmask)
