@@ -141,8 +141,41 @@ class Seq2seq(BaseModel):
                        'f_cyc_gen_error: {:.4f}').format(self.now_batch, np.mean(d_hist), f[0], f[1], f[2], f[3], f[4],
                                                           temperature, f[5], f[6]))
 
+    def transfer(self, incoming, domain=None, temperature=1.0, *, use_inference_z=True):
+        """The generator's share of `evaluate` (seq2seq.py:303-339): greedy style transfer of one batch, without the cotk
+        metrics and the RoBERTa classifier around it.
+        incoming.data.{sent [B,L], sent_length [B]}; domain = source style of the batch (int) or None to read
+        incoming.data.domain.  Returns a Storage with
+          gen [B,T] int64     argmax tokens of the transferred sentences (`rev_log_probs.argmax(-1)`, :324)
+          gen_lengths [B]     generated lengths (learnable alignment) or None
+          allpos              list of B int64 arrays `pos[1:glen+1]` (:337-338) or None
+          length_delta        mean(gen_lengths - inp_lengths) (:343) or None
+        Runs the padded execution, so every position holds the reference's value."""
+        inp_tokens, inp_lengths = incoming.data.sent, incoming.data.sent_length
+        raw_styles = torch.full_like(inp_tokens[:, 0], domain) if domain is not None else incoming.data.domain
+        was_training = self.net.model_F.training
+        self.net.model_F.eval()
+        try:
+            with torch.no_grad(), ops.packed_rows(False):
+                log_probs, gen_lengths, _, _, allpos = self.net.model_F(
+                    inp_tokens, inp_lengths, None, None, 1 - raw_styles, generate=True, differentiable_decode=False,
+                    temperature=temperature, use_inference_z=use_inference_z)
+                out = Storage()
+                out.gen = log_probs.argmax(-1)
+        finally:
+            self.net.model_F.train(was_training)
+        out.gen_lengths, out.allpos, out.length_delta = None, None, None
+        if self.args.use_learnable:
+            glen = gen_lengths.cpu().numpy()
+            pos = allpos.cpu().numpy()
+            out.gen_lengths = gen_lengths
+            out.allpos = [p[1:g + 1] for g, p in zip(glen, pos)]
+            out.length_delta = float(np.mean(glen - inp_lengths.cpu().numpy()))
+        return out
+
     def evaluate(self, *a, **k):
-        raise NotImplementedError("evaluate needs cotk metrics + the RoBERTa classifier (out of scope, SURVEY 2.1)")
+        raise NotImplementedError("evaluate needs cotk metrics + the RoBERTa classifier (out of scope, SURVEY 2.1); "
+                                  "Seq2seq.transfer() is the generator's share of it")
 
     train_process = test_process = evaluate
 

@@ -372,3 +372,29 @@ def test_bench_shape_step_vs_oracle():
     got, ref, gn, gn_ref = _oracle_vs_hip_step(dict(V=9600, d=256, h=4, N=4, L=32, learnable=True), B=6)
     np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(gn, gn_ref, rtol=1e-3)
+
+
+def test_transfer_matches_golden_generate():
+    """Seq2seq.transfer (the generator's share of evaluate, seq2seq.py:303-339) on the captured generate case: argmax
+    tokens, generated lengths and alignment positions of the reference."""
+    import nast_amd.utils as U
+    from nast_amd.seq2seq import Seq2seq
+    from nast_amd.utils import Storage
+    g = load_golden("g2_style_transformer_learnable")
+    U.cuda_init(0, "cuda")
+    model = Seq2seq(make_param(device="cuda", **cfg_of(g)))
+    assert not load_weights(model.net.model_F, sub(g, "w/"))
+    gold, gl, style = T(g["in/gold"]), T(g["in/gold_len"]), T(g["in/style"])
+    inc = Storage(); inc.data = Storage()
+    inc.data.sent, inc.data.sent_length, inc.data.domain = gold, gl, style       # transferred to 1 - style
+    out = model.transfer(inc, temperature=1.0, use_inference_z=True)
+    ref_lp = g["out/generate/log_probs"]
+    glen = g["out/generate/tgt_lengths"]
+    assert np.array_equal(out.gen_lengths.cpu().numpy(), glen)
+    gen, ref_gen = out.gen.cpu().numpy(), ref_lp.argmax(-1)
+    for b in range(gen.shape[0]):                       # beyond the generated length the reference's ids are argmax of noise-level ties
+        assert np.array_equal(gen[b, :glen[b]], ref_gen[b, :glen[b]]), b
+    for b, pos in enumerate(out.allpos):
+        assert np.array_equal(pos, g["out/generate/allpos"][b][1:glen[b] + 1])
+    assert abs(out.length_delta - float(np.mean(glen - g["in/gold_len"]))) < 1e-6
+    assert model.net.model_F.training
