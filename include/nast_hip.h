@@ -282,12 +282,17 @@ int nast_lp_decode_f32(const nast_lp_decode_args* args, int* steps_out, void* st
  * ptrs are device arrays of device pointers (one entry per parameter tensor), sizes int64 element counts.
  * ---------------------------------------------------------------------------------------------- */
 int nast_multi_sqnorm_f32(const float* const* grads, const int64_t* sizes, int n, float* out_sq /*[1], +=*/,
+                          const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_elems,
                           void* stream);
 int nast_multi_adam_f32(float* const* params, float* const* grads /* scaled in place by the clip */, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* sizes, int n,
                         const float* total_sqnorm /*device [1] or NULL*/, float max_norm,
                         float lr, float beta1, float beta2, float eps, float weight_decay,
-                        float bias_c1, float bias_c2, void* stream);
+                        float bias_c1, float bias_c2,
+                        const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_elems,
+                        void* stream);
+/* chunk table (device arrays, or NULL for a (32, n) grid): chunk c covers elements chunk_off[c] .. +chunk_elems of tensor
+ * chunk_tensor[c]; one workgroup per chunk, so tensors of very different sizes load the chip evenly. */
 
 /* ------------------------------------------------------------------------------------------------
  * In-library kernel timing (HIP events on the caller's stream) for bench.py's roofline block.

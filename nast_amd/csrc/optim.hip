@@ -1,15 +1,42 @@
 // Multi-tensor gradient-norm + clip + Adam (seq2seq.py:536-537, :637-638): two launches for the whole
-// parameter group instead of ~4 launches per tensor.  grid = (32, n_tensors), grid-stride inside a tensor.
+// parameter group instead of ~4 launches per tensor.  Work is dealt in chunks of `chunk_elems` consecutive elements of one
+// tensor (table built by the caller: chunk -> tensor, first element), one workgroup per chunk, so the three 2.4 M-element
+// embedding / generator matrices spread over the chip like the 260 small tensors do (a (32, n_tensors) grid left them on
+// 32 workgroups each: 1 TB/s).  Without a table: grid = (32, n_tensors), grid-stride inside a tensor.
 #include "common.h"
 
+struct ChunkRange {
+  int tensor;
+  int64_t lo, hi, step;
+};
+__device__ __forceinline__ ChunkRange chunk_range(const int32_t* __restrict__ chunk_tensor, const int64_t* __restrict__ chunk_off,
+                                                  int chunk_elems, const int64_t* __restrict__ sizes) {
+  ChunkRange r;
+  if (chunk_tensor != nullptr) {
+    r.tensor = chunk_tensor[blockIdx.x];
+    const int64_t n = sizes[r.tensor];
+    r.lo = chunk_off[blockIdx.x] + threadIdx.x;
+    r.hi = chunk_off[blockIdx.x] + chunk_elems < n ? chunk_off[blockIdx.x] + chunk_elems : n;
+    r.step = 256;
+  } else {
+    r.tensor = blockIdx.y;
+    r.lo = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    r.hi = sizes[r.tensor];
+    r.step = (int64_t)gridDim.x * 256;
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(256) void nast_multi_sqnorm_kernel(const float* const* __restrict__ grads,
-                                                                const int64_t* __restrict__ sizes, float* __restrict__ out_sq) {
+                                                                const int64_t* __restrict__ sizes, float* __restrict__ out_sq,
+                                                                const int32_t* __restrict__ chunk_tensor,
+                                                                const int64_t* __restrict__ chunk_off, int chunk_elems) {
   __shared__ double red[4];
-  const float* g = grads[blockIdx.y];
-  const int64_t n = sizes[blockIdx.y];
+  const ChunkRange R = chunk_range(chunk_tensor, chunk_off, chunk_elems, sizes);
+  const float* g = grads[R.tensor];
   double s = 0.0;                                // fp64 partial sums: the kernel is memory-bound, the adds are free
   if (g)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)g[i] * (double)g[i];
+    for (int64_t i = R.lo; i < R.hi; i += R.step) s += (double)g[i] * (double)g[i];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -24,13 +51,15 @@ __global__ __launch_bounds__(256) void nast_multi_adam_kernel(float* const* __re
                                                               float* const* __restrict__ exp_avg, float* const* __restrict__ exp_avg_sq,
                                                               const int64_t* __restrict__ sizes, const float* __restrict__ total_sq,
                                                               float max_norm, float lr, float beta1, float beta2, float eps,
-                                                              float weight_decay, float bias_c1, float bias_c2) {
-  float* g = grads[blockIdx.y];
+                                                              float weight_decay, float bias_c1, float bias_c2,
+                                                              const int32_t* __restrict__ chunk_tensor,
+                                                              const int64_t* __restrict__ chunk_off, int chunk_elems) {
+  const ChunkRange R = chunk_range(chunk_tensor, chunk_off, chunk_elems, sizes);
+  float* g = grads[R.tensor];
   if (!g) return;
-  float* p = params[blockIdx.y];
-  float* m = exp_avg[blockIdx.y];
-  float* v = exp_avg_sq[blockIdx.y];
-  const int64_t n = sizes[blockIdx.y];
+  float* p = params[R.tensor];
+  float* m = exp_avg[R.tensor];
+  float* v = exp_avg_sq[R.tensor];
   float coef = 1.f;
   if (total_sq) {
     // torch.nn.utils.clip_grad_norm_: coef = clamp(max_norm / (norm + 1e-6), max=1)
@@ -41,7 +70,7 @@ __global__ __launch_bounds__(256) void nast_multi_adam_kernel(float* const* __re
   const float step = lr / bias_c1;
   const float bc2_sqrt = sqrtf(bias_c2);
   const float w1 = 1.f - beta1, w2 = 1.f - beta2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = R.lo; i < R.hi; i += R.step) {
     float gi = g[i];
     if (total_sq) {
       gi *= coef;
@@ -57,23 +86,31 @@ __global__ __launch_bounds__(256) void nast_multi_adam_kernel(float* const* __re
   }
 }
 
-extern "C" int nast_multi_sqnorm_f32(const float* const* grads, const int64_t* sizes, int n, float* out_sq, void* stream) {
+extern "C" int nast_multi_sqnorm_f32(const float* const* grads, const int64_t* sizes, int n, float* out_sq, const int32_t* chunk_tensor,
+                                     const int64_t* chunk_off, int n_chunks, int chunk_elems, void* stream) {
   NAST_REQUIRE(n >= 0 && n <= 65535, "nast_multi_sqnorm_f32: n=%d out of range", n);
   if (n == 0) return NAST_OK;
   NAST_REQUIRE(grads && sizes && out_sq, "nast_multi_sqnorm_f32: NULL pointer");
-  hipLaunchKernelGGL(nast_multi_sqnorm_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, grads, sizes, out_sq);
+  NAST_REQUIRE(chunk_tensor == nullptr || (chunk_off != nullptr && n_chunks > 0 && chunk_elems > 0), "nast_multi_sqnorm_f32: chunk table");
+  const dim3 grid = chunk_tensor ? dim3(n_chunks) : dim3(32, n);
+  hipLaunchKernelGGL(nast_multi_sqnorm_kernel, grid, dim3(256), 0, (hipStream_t)stream, grads, sizes, out_sq, chunk_tensor, chunk_off,
+                     chunk_elems);
   NAST_CHECK_LAUNCH("nast_multi_sqnorm_f32");
   return NAST_OK;
 }
 
 extern "C" int nast_multi_adam_f32(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                                    const int64_t* sizes, int n, const float* total_sqnorm, float max_norm, float lr, float beta1,
-                                   float beta2, float eps, float weight_decay, float bias_c1, float bias_c2, void* stream) {
+                                   float beta2, float eps, float weight_decay, float bias_c1, float bias_c2, const int32_t* chunk_tensor,
+                                   const int64_t* chunk_off, int n_chunks, int chunk_elems, void* stream) {
   NAST_REQUIRE(n >= 0 && n <= 65535, "nast_multi_adam_f32: n=%d out of range", n);
   if (n == 0) return NAST_OK;
   NAST_REQUIRE(params && grads && exp_avg && exp_avg_sq && sizes, "nast_multi_adam_f32: NULL pointer");
-  hipLaunchKernelGGL(nast_multi_adam_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                     sizes, total_sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2);
+  NAST_REQUIRE(chunk_tensor == nullptr || (chunk_off != nullptr && n_chunks > 0 && chunk_elems > 0), "nast_multi_adam_f32: chunk table");
+  const dim3 grid = chunk_tensor ? dim3(n_chunks) : dim3(32, n);
+  hipLaunchKernelGGL(nast_multi_adam_kernel, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                     sizes, total_sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, chunk_tensor, chunk_off,
+                     chunk_elems);
   NAST_CHECK_LAUNCH("nast_multi_adam_f32");
   return NAST_OK;
 }

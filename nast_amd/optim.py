@@ -19,6 +19,8 @@ from . import ops
 
 
 class FusedAdam(optim.Adam):
+    CHUNK = 16384            # elements per workgroup of the multi-tensor kernels
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **kw):
         if kw.get("amsgrad") or kw.get("maximize") or kw.get("capturable") or kw.get("differentiable"):
             raise NotImplementedError("FusedAdam: amsgrad / maximize / capturable / differentiable are not supported")
@@ -46,9 +48,14 @@ class FusedAdam(optim.Adam):
             dev = plist[0].device
             cols = list(zip(*key))
             ptrs = torch.tensor(cols, dtype=torch.int64).to(dev)                  # [4, n] device pointers
-            sizes = torch.tensor([p.numel() for p in plist], dtype=torch.int64).to(dev)
+            numels = [p.numel() for p in plist]
+            sizes = torch.tensor(numels, dtype=torch.int64).to(dev)
             sq = torch.zeros(1, device=dev, dtype=torch.float32)
-            ent = (key, ptrs, sizes, sq)
+            # work table: chunks of CHUNK consecutive elements of one tensor, one workgroup each
+            ct = [t for t, n in enumerate(numels) for _ in range(0, n, self.CHUNK)]
+            co = [o for n in numels for o in range(0, n, self.CHUNK)]
+            chunks = (torch.tensor(ct, dtype=torch.int32).to(dev), torch.tensor(co, dtype=torch.int64).to(dev), len(ct))
+            ent = (key, ptrs, sizes, sq, chunks)
             self._tables[gi] = ent
         return ent
 
@@ -80,8 +87,9 @@ class FusedAdam(optim.Adam):
             sq.zero_()
             for t in tabs:
                 if t is not None:
-                    _, ptrs, sizes, _ = t
-                    ops.call("nast_multi_sqnorm_f32", ptrs[1].data_ptr(), sizes.data_ptr(), sizes.numel(), sq.data_ptr(), stream)
+                    _, ptrs, sizes, _, (ct, co, nc) = t
+                    ops.call("nast_multi_sqnorm_f32", ptrs[1].data_ptr(), sizes.data_ptr(), sizes.numel(), sq.data_ptr(),
+                             ct.data_ptr(), co.data_ptr(), nc, self.CHUNK, stream)
         for g, pl, t in zip(self.param_groups, plists, tabs):
             if t is None:
                 continue
@@ -92,9 +100,10 @@ class FusedAdam(optim.Adam):
             for p in pl:
                 self.state[p]["step"] += 1
             b1, b2 = g["betas"]
-            _, ptrs, sizes, _ = t
+            _, ptrs, sizes, _, (ct, co, nc) = t
             ops.call("nast_multi_adam_f32", ptrs[0].data_ptr(), ptrs[1].data_ptr(), ptrs[2].data_ptr(), ptrs[3].data_ptr(),
                      sizes.data_ptr(), sizes.numel(), sq.data_ptr() if sq is not None else None,
                      float(max_norm) if max_norm is not None else 0.0, float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-                     float(g["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, stream)
+                     float(g["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, ct.data_ptr(), co.data_ptr(), nc, self.CHUNK,
+                     stream)
         return sq.sqrt().reshape(()) if sq is not None else None
