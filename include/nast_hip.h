@@ -275,6 +275,9 @@ typedef struct nast_lp_decode_args {
 } nast_lp_decode_args;
 
 int64_t nast_lp_decode_workspace_bytes(int B, int S1, int d, int dff, int L, int nlayers);
+/* steps_out: number of decode steps taken (allpos columns 1..steps are valid).  On entry *steps_out >= 0: the reference's
+ * early exit (every 5th step the progress is read back, transformer.py:569 -- the call synchronises the stream);
+ * *steps_out < 0: no read-back, all L steps are enqueued and the call returns at once (steps = L). */
 int nast_lp_decode_f32(const nast_lp_decode_args* args, int* steps_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -103,6 +103,9 @@ extern "C" int64_t nast_lp_decode_workspace_bytes(int B, int S1, int d, int dff,
 extern "C" int nast_lp_decode_f32(const nast_lp_decode_args* A, int* steps_out, void* stream_) {
   hipStream_t s = (hipStream_t)stream_;
   NAST_REQUIRE(A && steps_out, "nast_lp_decode_f32: NULL args");
+  // *steps_out < 0 on entry: never read the progress back -- all L steps are enqueued and the call returns without
+  // synchronising (positions of finished sentences stay put, so the result's leading columns are the same)
+  const bool early_exit = *steps_out >= 0;
   const int B = A->B, S1 = A->S1, d = A->d, h = A->h, dff = A->dff, L = A->L, nl = A->nlayers;
   NAST_REQUIRE(B >= 1 && S1 >= 1 && d >= 1 && L >= 1 && nl >= 1 && nl <= 8 && h >= 1 && d % h == 0, "nast_lp_decode_f32: bad sizes");
   NAST_REQUIRE(h <= 64, "nast_lp_decode_f32: h > 64");
@@ -199,7 +202,7 @@ extern "C" int nast_lp_decode_f32(const nast_lp_decode_args* A, int* steps_out, 
                          A->norm_w, A->norm_b, B, S1, d, k, L + 1, k + 1 < L ? 1 : 0, s));
     float* t = x; x = xn; xn = t;
     steps = k + 1;
-    if (k % 5 == 0) {   // transformer.py:569: stop once every sentence has consumed its source
+    if (early_exit && k % 5 == 0) {   // transformer.py:569: stop once every sentence has consumed its source
       hipLaunchKernelGGL(lp_count_done_kernel, dim3(1), dim3(64), 0, s, w.now_pos, A->origin_length, w.done, B);
       int done = 0;
       if (hipMemcpyAsync(&done, w.done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {

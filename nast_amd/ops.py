@@ -412,6 +412,44 @@ def layer_norm_rows(x, gamma, beta, grp, grp_stride, grp_off, rows_out):
 
 
 # ------------------------------------------------------------------------------------------------
+# host work deferred into the shadow of the greedy decode
+# ------------------------------------------------------------------------------------------------
+# The greedy skip decoding is ~800 tiny dependent launches: ~9 ms during which the GPU is almost idle and the host, which
+# needs the generated lengths next, can only wait.  With ASYNC_DECODE the decode is enqueued without its early-exit
+# read-backs, and `run_deferred()` -- called by LengthPredictor right after that enqueue -- runs a callable the training
+# step left in `defer`: the step uses it to issue the whole self-reconstruction pass on the main stream, so the decode
+# (side stream) executes beside real work and is finished by the time the host asks for the lengths.
+ASYNC_DECODE = False
+_deferred = None
+
+
+class async_decode:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global ASYNC_DECODE, _deferred
+        self.prev = (ASYNC_DECODE, _deferred)
+        ASYNC_DECODE, _deferred = True, self.fn
+        return self
+
+    def __exit__(self, *exc):
+        global ASYNC_DECODE, _deferred
+        pending = _deferred
+        ASYNC_DECODE, _deferred = self.prev
+        if pending is not None and exc[0] is None:
+            pending()                      # nobody reached the decode (e.g. no length predictor): run it now
+
+
+def run_deferred():
+    global _deferred
+    fn, _deferred = _deferred, None
+    if fn is not None:
+        with torch.enable_grad():
+            fn()
+
+
+# ------------------------------------------------------------------------------------------------
 # packed rows: the position-wise work of a ragged batch without its padding
 # ------------------------------------------------------------------------------------------------
 # A [B, n, d] batch of sentences of lengths len[b] <= n spends n - len[b] rows per sentence on padding that every

@@ -262,35 +262,33 @@ class Seq2seq(BaseModel):
 
         model_F = self.net.model_F
         # The transfer pass (seq2seq.py:476-490), the cycle pass forward and the discriminator forward depend on nothing the
-        # self-reconstruction pass produces (backward #1 only adds to .grad).  They are issued on a second HIP stream after
-        # the whole first pass (forward + backward #1) has been enqueued on the main stream; the streams are ordered both
-        # ways before backward #2 and joined after it.  (Small batches are bound by the host launch rate, where a second
-        # stream only adds synchronisation: measured 33 -> 37 ms at 64 sentences.)
+        # self-reconstruction pass produces (backward #1 only adds to .grad): they go to a second HIP stream; the streams are
+        # ordered both ways before backward #2 and joined after it.  (Small batches are bound by the host launch rate, where a
+        # second stream only adds synchronisation: measured 33 -> 37 ms at 64 sentences.)
         overlap = self.overlap_passes and cyc_rec_enable and inp_tokens.is_cuda and inp_tokens.numel() >= self.overlap_min_tokens
-        if overlap:
-            main = torch.cuda.current_stream()
-            side = self._side_stream(inp_tokens.device)
-            side.wait_stream(main)          # inputs are ready; nothing of pass 1 is enqueued yet
-        # nll_targets: Generator + NLLLoss(reduction='none') (seq2seq.py:453) run as one node on the device
-        slf_nll, _, slf_length_losses, slf_gen_error, _ = model_F(
-            noise_inp_tokens, noise_inp_lengths, inp_tokens, inp_lengths, raw_styles,
-            generate=False, differentiable_decode=False, temperature=temperature, use_inference_z=use_inference_z,
-            nll_targets=inp_tokens)
-        slf_rec_loss = slf_nll * token_mask
-        slf_rec_loss = slf_rec_loss.sum() / batch_size
-        slf_rec_loss = slf_rec_loss * args.slf_factor
 
-        last_backward = not cyc_rec_enable
-        if last_backward:
-            self.reducer_F.arm("f_pretrain")
-        if args.use_learnable:
-            slf_rec_length_loss = self._length_loss(slf_length_losses, inp_lengths, batch_size)
-            (slf_rec_loss + slf_rec_length_loss).backward()
-        else:
-            slf_rec_length_loss = None
-            slf_rec_loss.backward()
+        def self_pass():
+            """self-reconstruction pass: forward + backward #1 (seq2seq.py:440-464)"""
+            # nll_targets: Generator + NLLLoss(reduction='none') (seq2seq.py:453) run as one node on the device
+            slf_nll, _, slf_length_losses, slf_gen_error, _ = model_F(
+                noise_inp_tokens, noise_inp_lengths, inp_tokens, inp_lengths, raw_styles,
+                generate=False, differentiable_decode=False, temperature=temperature, use_inference_z=use_inference_z,
+                nll_targets=inp_tokens)
+            slf_rec_loss = slf_nll * token_mask
+            slf_rec_loss = slf_rec_loss.sum() / batch_size
+            slf_rec_loss = slf_rec_loss * args.slf_factor
+            if not cyc_rec_enable:
+                self.reducer_F.arm("f_pretrain")
+            if args.use_learnable:
+                slf_rec_length_loss = self._length_loss(slf_length_losses, inp_lengths, batch_size)
+                (slf_rec_loss + slf_rec_length_loss).backward()
+            else:
+                slf_rec_length_loss = None
+                slf_rec_loss.backward()
+            return slf_rec_loss, slf_rec_length_loss, slf_gen_error
 
         if not cyc_rec_enable:                                                 # seq2seq.py:471-474 (no clipping here)
+            slf_rec_loss, slf_rec_length_loss, slf_gen_error = self_pass()
             self.reducer_F.finish()
             self.optimizer_F.clip_and_step(None)
             self.net.model_D.train()
@@ -347,15 +345,28 @@ class Seq2seq(BaseModel):
             return total, cyc_rec_loss, cyc_rec_length_loss, cyc_gen_error, adv_loss
 
         if overlap:
-            # all of it is issued on the side stream: the transfer pass runs beside the self-reconstruction forward,
-            # the cycle pass forward beside backward #1 (it reads parameters only; backward #1 only adds to .grad)
-            with torch.cuda.stream(side):
+            # Issue order on the host: transfer-pass encoder and the greedy decode (asynchronous: no early-exit read-backs)
+            # on the side stream, then -- from the hook LengthPredictor calls right after enqueuing the decode -- the whole
+            # self-reconstruction pass on the main stream, then the rest of the side stream's work.  The decode's ~9 ms of
+            # tiny dependent launches thus run beside pass 1 instead of holding up the host and an idle GPU.
+            main = torch.cuda.current_stream()
+            side = self._side_stream(inp_tokens.device)
+            side.wait_stream(main)          # inputs are ready
+            first = {}
+
+            def issue_self_pass():
+                with torch.cuda.stream(main):
+                    first["ret"] = self_pass()
+
+            with ops.async_decode(issue_self_pass), torch.cuda.stream(side):
                 total, cyc_rec_loss, cyc_rec_length_loss, cyc_gen_error, adv_loss = cycle_forward()
+            slf_rec_loss, slf_rec_length_loss, slf_gen_error = first["ret"]
             # backward #2 runs on the side stream (the stream of its nodes' forward) and adds to the .grad buffers
             # backward #1 created and filled on the main stream: order the two streams both ways before it starts
             main.wait_stream(side)
             side.wait_stream(main)
         else:
+            slf_rec_loss, slf_rec_length_loss, slf_gen_error = self_pass()
             total, cyc_rec_loss, cyc_rec_length_loss, cyc_gen_error, adv_loss = cycle_forward()
 
         self.reducer_F.arm("f_full", streams=(main, side) if overlap else ())

@@ -575,8 +575,9 @@ class LengthPredictor(nn.Module):
         a.memory, a.origin_length, a.allpos = memory.data_ptr(), origin_length.data_ptr(), allpos_buf.data_ptr()
         off = (-ws.data_ptr()) % 256
         a.workspace = ws.data_ptr() + off
-        steps = C.c_int(0)
+        steps = C.c_int(-1 if ops.ASYNC_DECODE else 0)       # -1: no early-exit read-backs, the call does not synchronise
         ops.call("nast_lp_decode_f32", C.byref(a), C.byref(steps), ops._stream())
+        self._decode_keepalive = (ws, memory, eos, unk)       # the enqueued kernels still read them
         return steps.value
 
     # -- forward ------------------------------------------------------------------------------
@@ -635,6 +636,7 @@ class LengthPredictor(nn.Module):
         with torch.no_grad():
             allpos_buf = torch.empty(batch_size, L + 1, dtype=torch.long, device=dev)
             steps = self._native_decode(origin_input.detach(), origin_length, eos_embed.detach(), unk_embed.detach(), allpos_buf)
+            ops.run_deferred()       # host work that can proceed while the decode runs (ops.async_decode)
             allpos = allpos_buf[:, :steps + 1].contiguous()
         dec_input = ops.lp_gather(origin_input, origin_length, allpos, eos_embed, unk_embed, None, 0, True)   # :576-578
         target_length = (allpos < (origin_length + 1).unsqueeze(-1)).sum(dim=1) - 1                  # :580
