@@ -44,8 +44,14 @@ class Seq2seq(BaseModel):
     overlap_passes = True      # f_step: run the transfer pass on a second stream beside pass 1 (set False to serialise)
     _streams = None
 
-    overlap_min_tokens = 4096
+    # tokens per step from which the second stream is used: always with the length predictor (its decode hook pays even at
+    # 64 sentences: 24.8 -> 22.9 ms), from 4096 tokens without it (host-launch bound below).  An int sets both.
+    overlap_min_tokens = {"learnable": 0, "simple": 4096}
     merge_generate_max = 1024   # d_step: generate both styles as one batch while 2B stays on the decode's small-M path
+
+    def _overlap_threshold(self):
+        t = self.overlap_min_tokens
+        return t["learnable" if self.args.use_learnable else "simple"] if isinstance(t, dict) else t
 
     def _side_stream(self, device):
         if self._streams is None:
@@ -265,7 +271,7 @@ class Seq2seq(BaseModel):
         # self-reconstruction pass produces (backward #1 only adds to .grad): they go to a second HIP stream; the streams are
         # ordered both ways before backward #2 and joined after it.  (Small batches are bound by the host launch rate, where a
         # second stream only adds synchronisation: measured 33 -> 37 ms at 64 sentences.)
-        overlap = self.overlap_passes and cyc_rec_enable and inp_tokens.is_cuda and inp_tokens.numel() >= self.overlap_min_tokens
+        overlap = self.overlap_passes and cyc_rec_enable and inp_tokens.is_cuda and inp_tokens.numel() >= self._overlap_threshold()
 
         def self_pass():
             """self-reconstruction pass: forward + backward #1 (seq2seq.py:440-464)"""
@@ -402,7 +408,7 @@ class Seq2seq(BaseModel):
 
         # The discriminator's forward on the gold sentences needs nothing from the generator: it is issued on the second
         # stream first, so it fills the CUs that the latency-bound generation (greedy decode) leaves idle.
-        overlap = self.overlap_passes and inp_tokens.is_cuda and inp_tokens.numel() >= self.overlap_min_tokens
+        overlap = self.overlap_passes and inp_tokens.is_cuda and inp_tokens.numel() >= self._overlap_threshold()
 
         def gold_forward():
             if args.discriminator_method == 'Multi':
