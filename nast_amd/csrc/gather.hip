@@ -51,6 +51,11 @@ __global__ __launch_bounds__(256) void nast_embed_bwd_tok_kernel(const float* __
   const float* g = dout + ((int64_t)b * (ne + L) + ne + i) * d;
   if (ids) {
     if (d_tokw) {
+      // rows whose gradient is all zero add nothing: skipped.  Padded positions carry no gradient, and they all hold the
+      // same id (<pad>), so their atomics would otherwise pile up on one table row (fp32 atomics on one address serialise).
+      bool any = false;
+      for (int c = lane; c < d; c += 64) any |= g[c] != 0.f;
+      if (__ballot(any) == 0ull) return;
       float* dst = d_tokw + ids[r] * d;
       for (int c = lane; c < d; c += 64) atomicAdd(dst + c, g[c]);
     }
