@@ -164,12 +164,15 @@ __global__ __launch_bounds__(256) void nast_lp_gather_fwd_kernel(const float* __
 // workgroup = (target position t, chunk of LP_BPB sentences).  Gradients of rows gathered from origin_input are
 // scattered with atomics (distinct addresses); the shared destinations (eos, unk, pos[t]) are first summed per
 // wavefront in registers -> one atomic per column per wavefront instead of one per sentence.
-#define LP_BPB 32
+#define LP_BPB 128
 __global__ __launch_bounds__(256) void nast_lp_gather_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ olen,
                                                                  const int64_t* __restrict__ allpos, float* __restrict__ d_oin,
                                                                  float* __restrict__ d_eos, float* __restrict__ d_unk,
                                                                  float* __restrict__ d_pos, int B, int S1, int T1, int d, int shift,
                                                                  int use_stay, int pos_skip_row0) {
+  // the three shared destinations see ONE atomic per column per workgroup (wavefront sums meet in LDS first): with
+  // 128 sentences per workgroup an address takes T1 * B / 128 adds instead of T1 * B / 8 (same-address atomics serialise)
+  __shared__ float red[3][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.x;
   const int b0 = blockIdx.y * LP_BPB;
@@ -181,21 +184,29 @@ __global__ __launch_bounds__(256) void nast_lp_gather_bwd_kernel(const float* __
     src[k] = b < B ? lp_source(allpos, olen, b, t, T1, S1, shift, use_stay) : -3;
   }
   const bool want_pos = d_pos && !(pos_skip_row0 && t == 0);
-  for (int c = lane; c < d; c += 64) {
+  for (int c0 = 0; c0 < d; c0 += 64) {
+    const int c = c0 + lane;
     float s_eos = 0.f, s_unk = 0.f, s_pos = 0.f;
+    if (c < d) {
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      const int b = b0 + wave + 4 * k;
-      if (src[k] == -3) continue;
-      const float v = dout[((int64_t)b * T1 + t) * d + c];
-      s_pos += v;
-      if (src[k] >= 0) { if (d_oin) atomicAdd(d_oin + ((int64_t)b * S1 + src[k]) * d + c, v); }
-      else if (src[k] == -1) s_eos += v;
-      else s_unk += v;
+      for (int k = 0; k < NB; ++k) {
+        const int b = b0 + wave + 4 * k;
+        if (src[k] == -3) continue;
+        const float v = dout[((int64_t)b * T1 + t) * d + c];
+        s_pos += v;
+        if (src[k] >= 0) { if (d_oin && v != 0.f) atomicAdd(d_oin + ((int64_t)b * S1 + src[k]) * d + c, v); }   // (padded positions: 0)
+        else if (src[k] == -1) s_eos += v;
+        else s_unk += v;
+      }
     }
-    if (s_eos != 0.f) atomicAdd(d_eos + c, s_eos);
-    if (s_unk != 0.f) atomicAdd(d_unk + c, s_unk);
-    if (want_pos) atomicAdd(d_pos + (int64_t)t * d + c, s_pos);
+    red[0][wave][lane] = s_eos; red[1][wave][lane] = s_unk; red[2][wave][lane] = s_pos;
+    __syncthreads();
+    if (wave < 3 && c < d) {
+      const float v = red[wave][0][lane] + red[wave][1][lane] + red[wave][2][lane] + red[wave][3][lane];
+      float* dst = wave == 0 ? d_eos + c : (wave == 1 ? d_unk + c : (want_pos ? d_pos + (int64_t)t * d + c : nullptr));
+      if (dst != nullptr && v != 0.f) atomicAdd(dst, v);
+    }
+    __syncthreads();
   }
 }
 

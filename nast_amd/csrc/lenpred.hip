@@ -112,32 +112,46 @@ __global__ __launch_bounds__(256) void nast_lp_logits_fwd_kernel(const float* __
 
 // workgroup = (position t, chunk of 32 sentences): dqh written, dKC scattered with atomics (distinct rows), the shared
 // dkunk summed per wavefront first (one atomic per column per wavefront)
-#define LPL_BPB 32
+#define LPL_BPB 128
 __global__ __launch_bounds__(256) void nast_lp_logits_bwd_kernel(const float* __restrict__ g, const float* __restrict__ qh,
                                                                  const float* __restrict__ KC, const float* __restrict__ kunk,
                                                                  const int64_t* __restrict__ allpos, float* __restrict__ dqh,
                                                                  float* __restrict__ dKC, float* __restrict__ dkunk, int B, int T1,
                                                                  int NC, int d, float inv) {
+  __shared__ float red[4][64];      // the kunk gradient: one atomic per column per workgroup
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.x;
   const int b0 = blockIdx.y * LPL_BPB;
-  for (int c = lane; c < d; c += 64) {
+  for (int c0 = 0; c0 < d; c0 += 64) {
+    const int c = c0 + lane;
     float s_unk = 0.f;
-    const float ku = kunk[c];
-    for (int b = b0 + wave; b < B && b < b0 + LPL_BPB; b += 4) {
-      const int64_t row = (int64_t)b * T1 + t;
-      const float4 gv = *reinterpret_cast<const float4*>(g + row * 4);
-      const int64_t a = allpos[row];
-      const float qv = qh[row * d + c];
-      const float* k1 = KC + ((int64_t)b * NC + a + 1) * d + c;
-      dqh[row * d + c] = inv * (gv.x * ku + gv.y * k1[0] + gv.z * k1[d] + gv.w * k1[2 * d]);
-      s_unk = fmaf(gv.x, qv, s_unk);
-      float* dk1 = dKC + ((int64_t)b * NC + a + 1) * d + c;
-      atomicAdd(dk1, inv * gv.y * qv);
-      atomicAdd(dk1 + d, inv * gv.z * qv);
-      atomicAdd(dk1 + 2 * d, inv * gv.w * qv);
+    if (c < d) {
+      const float ku = kunk[c];
+      for (int b = b0 + wave; b < B && b < b0 + LPL_BPB; b += 4) {
+        const int64_t row = (int64_t)b * T1 + t;
+        const float4 gv = *reinterpret_cast<const float4*>(g + row * 4);
+        if (gv.x == 0.f && gv.y == 0.f && gv.z == 0.f && gv.w == 0.f) {   // positions past the sentence carry no loss
+          dqh[row * d + c] = 0.f;
+          continue;
+        }
+        const int64_t a = allpos[row];
+        const float qv = qh[row * d + c];
+        const float* k1 = KC + ((int64_t)b * NC + a + 1) * d + c;
+        dqh[row * d + c] = inv * (gv.x * ku + gv.y * k1[0] + gv.z * k1[d] + gv.w * k1[2 * d]);
+        s_unk = fmaf(gv.x, qv, s_unk);
+        float* dk1 = dKC + ((int64_t)b * NC + a + 1) * d + c;
+        atomicAdd(dk1, inv * gv.y * qv);
+        atomicAdd(dk1 + d, inv * gv.z * qv);
+        atomicAdd(dk1 + 2 * d, inv * gv.w * qv);
+      }
     }
-    atomicAdd(dkunk + c, inv * s_unk);
+    red[wave][lane] = s_unk;
+    __syncthreads();
+    if (wave == 0 && c < d) {
+      const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+      if (v != 0.f) atomicAdd(dkunk + c, inv * v);
+    }
+    __syncthreads();
   }
 }
 

@@ -167,6 +167,9 @@ def zeros_like_many(tensors):
 # autograd's post-accumulate hooks do not fire for gradients that never pass through AccumulateGrad.
 INPLACE_GRADS = True
 grad_listener = None
+# Streams whose backward nodes add into the same .grad buffers (nast_amd.seq2seq: main + second stream).  A buffer that
+# is created lazily is zero-filled on ONE of them; the others must not start adding before that fill has run.
+peer_streams = ()
 
 
 def _sink(p):
@@ -174,6 +177,12 @@ def _sink(p):
         return None
     if p.grad is None:
         p.grad = torch.zeros_like(p)
+        if p.is_cuda and peer_streams:
+            cur = torch.cuda.current_stream(p.device)
+            for s in peer_streams:
+                if s != cur and s.device == p.device:
+                    s.wait_stream(cur)
+                    p.grad.record_stream(s)
     return p.grad
 
 

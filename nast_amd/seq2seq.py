@@ -64,6 +64,8 @@ class Seq2seq(BaseModel):
             quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
             if quiet is not None:
                 quiet(False)
+        # lazily created .grad buffers are zero-filled on one stream and added to from both (ops._sink)
+        ops.peer_streams = (torch.cuda.current_stream(device), self._streams[key])
         return self._streams[key]
 
     # ---- batches (seq2seq.py:108-164) ---------------------------------------------------------
