@@ -137,8 +137,16 @@ def main():
     backend = os.environ.get("NAST_DIST_BACKEND", "nccl")
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # NAST_DIST_SINGLE=1 is a rehearsal aid for a one-GPU box: a process group of ONE rank, so the bucketed all-reduce,
+    # the barrier and the max-over-ranks reduction go through RCCL's real launch path (nast_amd.ddp.FORCE_SINGLE)
+    dist_on = world > 1 or os.environ.get("NAST_DIST_SINGLE") == "1"
+    if dist_on:
         import torch.distributed as dist
+        if world == 1:
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
+            import nast_amd.ddp as _ddp
+            _ddp.FORCE_SINGLE = True
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -169,7 +177,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -179,7 +187,7 @@ def main():
     run(a.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -296,7 +304,7 @@ def main():
                     fams = [t[k] for k in keys if k in t]
                     if fams and name in hbm:
                         hbm[name]["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
-    if world > 1:
+    if dist_on:
         dist.barrier()
 
     if rank == 0:
@@ -328,7 +336,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, cfg, B)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 
 _reducers = []
+FORCE_SINGLE = False   # rehearsal aid: reduce even in a process group of one rank (exercises the RCCL path on a one-GPU box)
 ENABLED = True      # set False to build a model that takes no part in the process group (tests: single-process reference)
 
 
@@ -52,7 +53,7 @@ class GradReducer:
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.group = group
         self.bucket_bytes = bucket_bytes
-        self.enabled = ENABLED and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = ENABLED and dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_SINGLE)
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.armed = False
         self.plans = {}
