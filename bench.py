@@ -142,6 +142,9 @@ def main():
     dist_on = world > 1 or os.environ.get("NAST_DIST_SINGLE") == "1"
     if dist_on:
         import torch.distributed as dist
+        if os.environ.get("NAST_NO_RESERVE") != "1":
+            from nast_amd.seq2seq import reserve_streams
+            reserve_streams()        # before RCCL takes its hardware queues (see its docstring)
         if world == 1:
             for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
                 os.environ.setdefault(k, v)
@@ -306,6 +309,9 @@ def main():
                         hbm[name]["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
     if dist_on:
         dist.barrier()
+        if debug:
+            print(f"[rank {rank}] reducer F {model.reducer_F.stats} buckets "
+                  f"{ {k: [len(b) for b in p.buckets] for k, p in model.reducer_F.plans.items()} }", file=sys.stderr, flush=True)
 
     if rank == 0:
         sps = B * world * a.steps / elapsed

@@ -23,12 +23,14 @@ Local losses are divided by the LOCAL batch size (as the reference divides by it
 the gradients over ranks therefore equals the single-GPU gradient on the concatenated batch when all ranks
 hold equally many sentences.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 _reducers = []
 FORCE_SINGLE = False   # rehearsal aid: reduce even in a process group of one rank (exercises the RCCL path on a one-GPU box)
-ENABLED = True      # set False to build a model that takes no part in the process group (tests: single-process reference)
+ENABLED = os.environ.get("NAST_DDP_DISABLE") != "1"      # set False to build a model that takes no part in the process group (tests: single-process reference)
 
 
 def _listener(p):
@@ -61,6 +63,7 @@ class GradReducer:
         self.tag = None
         self._fired = []
         self._streams = ()
+        self.stats = {"learnt": 0, "overlapped": 0, "redone": 0}     # steps by how their reduce went
         if self.enabled:
             from . import ops
             for i, p in enumerate(self.params):
@@ -137,6 +140,12 @@ class GradReducer:
         return plan
 
     def _views(self, plan, b):
+        cache = plan.__dict__.setdefault("views", {})
+        if b not in cache:
+            cache[b] = self._make_views(plan, b)
+        return cache[b]
+
+    def _make_views(self, plan, b):
         out, off = [], 0
         for i in plan.buckets[b]:
             n = self.params[i].numel()
@@ -181,13 +190,17 @@ class GradReducer:
                 if w is not None:
                     w.wait()
             self.plan = None
+            self.stats["redone"] += 1
         if self.plan is None:
             if not self._fired:
                 return
+            self.stats["learnt"] += 1
             self.plan = self.plans[self.tag] = self._build_plan()
             n = len(self.plan.buckets)
             self._launched = [False] * n
             self._work = [None] * n
+        else:
+            self.stats["overlapped"] += 1
         for b in range(len(self.plan.buckets)):
             if not self._launched[b]:
                 self._launch(b)
