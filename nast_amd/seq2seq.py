@@ -9,6 +9,8 @@ Data parallelism (new; the reference is single-device): when torch.distributed i
 parameter group being stepped are averaged across ranks by nast_amd.ddp.GradReducer (bucketed all-reduce on
 RCCL, fired once per step during the LAST backward so that it overlaps with it) before clip + Adam.
 """
+import contextlib
+
 import numpy as np
 import torch
 from torch import nn, optim
@@ -428,8 +430,6 @@ class Seq2seq(BaseModel):
         if ops.PACK_ROWS and inp_lengths.is_cuda:
             ops.set_total(inp_lengths, inp_lengths.sum().item())
 
-        # The discriminator's forward on the gold sentences needs nothing from the generator: it is issued on the second
-        # stream first, so it fills the CUs that the latency-bound generation (greedy decode) leaves idle.
         overlap = self.overlap_passes and inp_tokens.is_cuda and inp_tokens.numel() >= self._overlap_threshold()
 
         def gold_forward():
@@ -438,15 +438,29 @@ class Seq2seq(BaseModel):
             return (torch.cat((model_D(inp_tokens, inp_lengths, raw_styles), model_D(inp_tokens, inp_lengths, rev_styles)), 0),
                     torch.cat((torch.ones_like(raw_styles), torch.zeros_like(rev_styles)), 0))
 
+        gold = {}
+        hook = contextlib.nullcontext()
         if overlap:
+            # The gold half of the loss needs nothing from the generator: its forward AND backward are issued on the second
+            # stream from the decode hook (ops.async_decode), right behind the enqueue of the greedy decode, so they fill
+            # the CUs that those ~800 small dependent launches leave idle.  adv_loss = gold part + generated part
+            # (seq2seq.py:632 sums over the concatenation); both parts add into the same .grad buffers.
             main = torch.cuda.current_stream()
             side = self._side_stream(inp_tokens.device)
+            self.optimizer_D.zero_grad(set_to_none=False)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                gold_log_probs, gold_labels = gold_forward()
+
+            def gold_pass():
+                with torch.cuda.stream(side):
+                    glp, glab = gold_forward()
+                    part = loss_fn(glp, glab).sum() / batch_size
+                    part.backward()
+                gold["loss"] = part.detach()
+
+            hook = ops.async_decode(gold_pass)
 
         both_packed = None
-        with torch.no_grad():
+        with hook, torch.no_grad():
             if inp_tokens.is_cuda and 2 * batch_size <= self.merge_generate_max:
                 # The two generation passes (seq2seq.py:565-580) differ only in the style token: they run as ONE batch of
                 # 2B sentences -- every op is per sentence, and the greedy skip decoding (latency-bound: ~800 small
@@ -510,22 +524,23 @@ class Seq2seq(BaseModel):
             gen_labels = torch.cat((torch.ones_like(raw_styles), torch.zeros_like(rev_styles)), 0)
 
         if overlap:
-            main.wait_stream(side)              # the gold half of the loss comes from the side stream
-            gold_log_probs.record_stream(main)
-            gold_labels.record_stream(main)
-        adv_log_probs = torch.cat((gold_log_probs, gen_log_probs), 0)
-        adv_labels = torch.cat((gold_labels, gen_labels), 0)
-        adv_loss = loss_fn(adv_log_probs, adv_labels)
-        assert len(adv_loss.size()) == 1
-        adv_loss = adv_loss.sum() / batch_size
+            assert len(gen_log_probs.size()) == 2
+            gen_part = loss_fn(gen_log_probs, gen_labels).sum() / batch_size
+            main.wait_stream(side)              # the gold pass ran during the decode; the two backwards never overlap
+            gold["loss"].record_stream(main)
+            self.reducer_D.arm("d")
+            gen_part.backward()
+            adv_loss = gold["loss"] + gen_part.detach()
+        else:
+            adv_log_probs = torch.cat((gold_log_probs, gen_log_probs), 0)
+            adv_labels = torch.cat((gold_labels, gen_labels), 0)
+            adv_loss = loss_fn(adv_log_probs, adv_labels)
+            assert len(adv_loss.size()) == 1
+            adv_loss = adv_loss.sum() / batch_size
 
-        self.optimizer_D.zero_grad(set_to_none=False)
-        if overlap:
-            side.wait_stream(main)              # its backward nodes add to the .grad buffers zeroed just above
-        self.reducer_D.arm("d", streams=(main, side) if overlap else ())
-        adv_loss.backward()
-        if overlap:
-            main.wait_stream(side)              # explicit join, as in f_step (no AccumulateGrad node lives on the side stream)
+            self.optimizer_D.zero_grad(set_to_none=False)
+            self.reducer_D.arm("d")
+            adv_loss.backward()
         self.reducer_D.finish()
         self.last_grad_norm = self.optimizer_D.clip_and_step(5)                # seq2seq.py:637-638
         model_F.train()
