@@ -220,13 +220,7 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
 
-        # the discriminator step (seq2seq.py:551-642) on the same batches
-        dt = timed(lambda i: model.d_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
-        also["d_step"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B}
-        f_ms = elapsed / a.steps
-        # SURVEY.md section 8d: the reference schedule runs 10 d_step per 5 f_step (run.py:133-134)
-        also["schedule_blend_10d_5f"] = {"value": round(15 * B / (10 * dt + 5 * f_ms), 2), "unit": "sentences/s"}
-        # ... and the step without its optimizer (clip + Adam skipped; forward + both backwards only)
+        # the step without its optimizer, measured right behind the headline pass (clip + Adam skipped; forward + both backwards only)
         step_fn = model.optimizer_F.clip_and_step
         model.optimizer_F.clip_and_step = lambda max_norm=None: None
         try:
@@ -234,6 +228,12 @@ def main():
         finally:
             model.optimizer_F.clip_and_step = step_fn
         also["fwd_bwd_only"] = {"value": round(B / dt_fb, 2), "unit": "sentences/s", "ms_per_step": round(dt_fb * 1e3, 3), "batch": B}
+        # the discriminator step (seq2seq.py:551-642) on the same batches
+        dt = timed(lambda i: model.d_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
+        also["d_step"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B}
+        f_ms = elapsed / a.steps
+        # SURVEY.md section 8d: the reference schedule runs 10 d_step per 5 f_step (run.py:133-134)
+        also["schedule_blend_10d_5f"] = {"value": round(15 * B / (10 * dt + 5 * f_ms), 2), "unit": "sentences/s"}
         # BASELINE.json configs[1]: simple alignment, YELP-shaped batch (64 sentences, len <= 16)
         cfg1 = dict(V=9600, d=256, h=4, N=4, L=16, learnable=False)
         m1 = build_model(cfg1, "cuda")
