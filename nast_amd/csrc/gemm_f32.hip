@@ -41,6 +41,7 @@ struct GemmLaunch {
   int kt_per_split[NAST_GEMM_MAX_GROUP];
   int count;
   int xcd_order;
+  int swz[NAST_GEMM_MAX_GROUP];   // chunk length of the per-problem XCD swizzle (0 = none)
 };
 
 template <int R, int BK>
@@ -411,7 +412,8 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
   // Optional XCD-contiguous order (NAST_GEMM_XCD=1): workgroups are dealt round-robin over the 8 XCDs, so making the
   // logical tile index contiguous per XCD lets the N/BN tiles that re-read one A row panel share an L2.  Measured:
   // +1..8 % on single-problem launches in tools/gemm_bench, but -7 % on the whole step (74.5 -> 80.4 ms): in the
-  // grouped launches (dgrad + wgrads) a contiguous slice per XCD gives the XCDs unequal work.  Default: off.
+  // grouped launches (dgrad + wgrads) a contiguous slice per XCD gives the XCDs unequal work.  Default: the per-problem
+  // chunked swizzle below (NAST_GEMM_XCD=3): same step time, L2-miss fetch traffic 204 -> 99 MB per launch.
   int bid = blockIdx.x;
   if (P.xcd_order) {
     const int n = gridDim.x, q = n >> 3, r = n & 7, x = blockIdx.x & 7;
@@ -420,7 +422,19 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
   int gi = 0;
   while (gi + 1 < P.count && bid >= P.tile_start[gi + 1]) ++gi;
   const nast_gemm_desc& D = P.d[gi];
-  const int local = bid - P.tile_start[gi];
+  int local = bid - P.tile_start[gi];
+  // Per-problem XCD swizzle (NAST_GEMM_XCD=3): inside chunks of 8 * tiles_n consecutive workgroups, the tiles_n tiles of one
+  // A row panel go to the workgroups of ONE XCD (blockIdx % 8) instead of one tile to each XCD, so the panel is fetched
+  // into one L2 instead of up to eight.  The launch order is only permuted inside a chunk: the balance of grouped
+  // launches (heavy split-K members first) is untouched, unlike the global order above.
+  if (const int C = P.swz[gi]) {
+    const int s0 = P.tile_start[gi], sa = (s0 + 7) & ~7;
+    const int rel = bid - sa;
+    if (rel >= 0) {
+      const int c = rel / C, r = rel - c * C;
+      if ((c + 1) * C <= P.tile_start[gi + 1] - sa) local = (sa - s0) + c * C + (r & 7) * (C >> 3) + (r >> 3);
+    }
+  }
   const int tn = local % P.tiles_n[gi];
   const int tq = local / P.tiles_n[gi];
   const int tm = tq % P.tiles_m[gi];
@@ -584,6 +598,11 @@ static void launch_skinny(const nast_gemm_desc* descs, int count, hipStream_t st
   hipLaunchKernelGGL(nast_gemm_f32_skinny_kernel, dim3(start), dim3(256), 0, stream, P);
 }
 
+static bool xcd_split_too(int sk) {   // tuning aid: NAST_GEMM_XCD_SPLIT=0 keeps split-K problems out of the swizzle
+  static const bool on = [] { const char* e = getenv("NAST_GEMM_XCD_SPLIT"); return e ? atoi(e) != 0 : true; }();
+  return sk == 1 || on;
+}
+
 template <int BM, int BN, int BK>
 static bool fast_ok(const nast_gemm_desc* descs, int count) {
   for (int i = 0; i < count; ++i) {
@@ -706,12 +725,22 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
     start += P.tiles_m[i] * P.tiles_n[i] * sk_of[i];
   }
   P = Q;
-  static const int xcd_order = [] { const char* e = getenv("NAST_GEMM_XCD"); return e ? atoi(e) : 0; }();   // tuning aid
+  static const int xcd_order = [] { const char* e = getenv("NAST_GEMM_XCD"); return e ? atoi(e) : 3; }();   // tuning aid (0 off, 1/2 global order, 3 per-problem chunks)
   // 2 = only for launches whose workgroups all do the same amount of work (one problem, or equal unsplit problems)
   bool uniform = true;
   for (int i = 0; i < count; ++i)
     uniform = uniform && P.splitk[i] == 1 && P.d[i].M == P.d[0].M && P.d[i].N == P.d[0].N && P.d[i].K == P.d[0].K && P.d[i].nsrc == P.d[0].nsrc;
-  P.xcd_order = xcd_order == 2 ? (uniform ? 1 : 0) : xcd_order;
+  P.xcd_order = xcd_order == 2 ? (uniform ? 1 : 0) : (xcd_order == 1 ? 1 : 0);
+  for (int i = 0; i < NAST_GEMM_MAX_GROUP; ++i) P.swz[i] = 0;
+  if (xcd_order == 3)
+    for (int i = 0; i < count; ++i)
+    {
+      // unsplit: a "panel" = the tiles_n tiles that share an A row panel; split-K: all tiles of one K slice (they share its
+      // A and B slices).  A panel goes to one XCD; a problem needs at least one full chunk of 8 panels to be touched at all.
+      const int panel = P.splitk[i] == 1 ? P.tiles_n[i] : P.tiles_m[i] * P.tiles_n[i];
+      const bool ok = P.splitk[i] == 1 ? (panel >= 2 && panel <= 32 && P.tiles_m[i] >= 16) : (panel >= 2 && panel <= 64 && P.splitk[i] >= 8);
+      if (ok && xcd_split_too(P.splitk[i])) P.swz[i] = 8 * panel;
+    }
   for (int i = count; i <= NAST_GEMM_MAX_GROUP; ++i) P.tile_start[i] = start;
   if (start == 0) return 0;
   bool bf16 = true;
