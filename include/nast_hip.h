@@ -210,6 +210,21 @@ int nast_align_lse_bwd_f32(const float* cost0, const float* cost, const int64_t*
                            const float* dvalue, float* dcost0, float* dcost, int B, int T, int S, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * NoiseLayer on the device (noise.py:60-194): blank -> add -> dropout/repeat of
+ * NoiseLayer.forward (:60-74) for a whole [S, B] time-major batch of ids, one lane per sentence.  Each stage is
+ * skipped when its uniform-draw pointer is NULL.  u_blank [S,B], u_add [M-1,B], new_words int64 [M,B] (the
+ * torch.multinomial candidates, :83), u_keep [M,B], u_rep [M-1,B], u_pick [B] (index = floor(u*n) when every word
+ * of a sentence was dropped, :150-152): float64 uniforms in [0,1).  out int64 [M+1, B] (rows past a sentence's new
+ * length hold pad after the dropout stage), out_len int64 [B].  M = max_length.  Integer work: bit-exact with the
+ * reference's per-sentence loops given the same draws.  Limits: M + 1 <= 160, S <= 160.                          */
+int nast_noise_i64(const int64_t* x, const int64_t* len, int S, int B, int M,
+                   const double* u_blank, double blank_prob,
+                   const double* u_add, const int64_t* new_words, double add_prob,
+                   const double* u_keep, const double* u_rep, const double* u_pick, double dropout_prob, double repeat_prob,
+                   int64_t pad, int64_t unk, int64_t eos, int keep_go, int keep_eos,
+                   int64_t* out, int64_t* out_len, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * LengthPredictor glue (transformer.py:466-519 teacher-forced, :527-582 greedy decode).
  * ---------------------------------------------------------------------------------------------- */
 /* cand(b,p) = origin_input[b,p] if p == 0 or (p < S1 and p-1 < len[b]) else eos            (:471-473)

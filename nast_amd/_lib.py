@@ -45,7 +45,7 @@ class Rows(C.Structure):
     _fields_ = [("ld", C.c_int64), ("grp", C.c_int64), ("grp_stride", C.c_int64)]
 
 
-_i, _i64, _f, _u64 = C.c_int, C.c_int64, C.c_float, C.c_uint64
+_i, _i64, _f, _u64, _d = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_double
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/nast_hip.h one to one
 SIGNATURES = {
@@ -69,6 +69,7 @@ SIGNATURES = {
     "nast_align_viterbi_f32": [c_fp] * 5 + [_i, _i, _i, c_fp],
     "nast_align_lse_fwd_f32": [c_fp] * 4 + [_f, c_fp, c_fp, _i, _i, _i, c_fp],
     "nast_align_lse_bwd_f32": [c_fp] * 4 + [_f] + [c_fp] * 5 + [_i, _i, _i, c_fp],
+    "nast_noise_i64": [c_fp, c_fp, _i, _i, _i, c_fp, _d, c_fp, c_fp, _d, c_fp, c_fp, c_fp, _d, _d, _i64, _i64, _i64, _i, _i, c_fp, c_fp, c_fp],
     "nast_lp_gather_fwd_f32": [c_fp] * 7 + [_i] * 6 + [c_fp],
     "nast_lp_gather_bwd_f32": [c_fp] * 7 + [_i] * 7 + [c_fp],
     "nast_lp_step_f32": [c_fp] * 15 + [_i] * 6 + [c_fp],

@@ -1107,3 +1107,28 @@ class LPLogitsFn(torch.autograd.Function):
 
 def lp_logits(qh, KC, kunk, allpos):
     return LPLogitsFn.apply(qh, KC, kunk, allpos)
+
+
+# ------------------------------------------------------------------------------------------------
+# NoiseLayer on the device (noise.py:60-194)
+# ------------------------------------------------------------------------------------------------
+def noise_tokens(x, lengths, max_length, *, u_blank=None, blank_prob=0.0, u_add=None, new_words=None, add_prob=0.0,
+                 u_keep=None, u_rep=None, u_pick=None, dropout_prob=0.0, repeat_prob=0.0, pad, unk, eos,
+                 keep_go=False, keep_eos=True):
+    """x int64 [S,B] (time-major), lengths int64 [B]; float64 uniform draws per stage (None = stage off).
+    -> (out int64 [max_length+1, B], new lengths int64 [B]); the caller cuts the width."""
+    S, B = x.shape
+    M = int(max_length)
+    for t, shape in ((u_blank, (S, B)), (u_add, (M - 1, B)), (new_words, (M, B)), (u_keep, (M, B)), (u_rep, (M - 1, B)), (u_pick, (B,))):
+        if t is not None and (tuple(t.shape) != shape or not t.is_contiguous() or not t.is_cuda):
+            raise _lib.NastHipError(f"noise_tokens: expected a contiguous device tensor of shape {shape}, got {tuple(t.shape)}")
+    for t in (u_blank, u_add, u_keep, u_rep, u_pick):
+        if t is not None and t.dtype != torch.float64:
+            raise _lib.NastHipError("noise_tokens: uniform draws must be float64")
+    x, lengths = _c(x), _c(lengths)
+    out = torch.empty(M + 1, B, dtype=torch.long, device=x.device)
+    out_len = torch.empty(B, dtype=torch.long, device=x.device)
+    call("nast_noise_i64", _p(x), _p(lengths), S, B, M, _p(u_blank), float(blank_prob), _p(u_add), _p(new_words), float(add_prob),
+         _p(u_keep), _p(u_rep), _p(u_pick), float(dropout_prob), float(repeat_prob), int(pad), int(unk), int(eos),
+         int(bool(keep_go)), int(bool(keep_eos)), _p(out), _p(out_len), _stream())
+    return out, out_len
