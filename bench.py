@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: train sentences/sec of the NAST-StyTrans (learnable alignment) generator training step.
 
-A "step" is one `Seq2seq.f_step` as the reference defines it (seq2seq.py:416-543): host NoiseLayer, three
+A "step" is one `Seq2seq.f_step` as the reference defines it (seq2seq.py:416-543): NoiseLayer (device kernel), three
 generator forward passes (self-reconstruction, transfer with greedy skip decoding, cycle reconstruction from
 Gumbel-softmax soft tokens), one discriminator forward, two backward passes, global-norm clip and Adam.
 
