@@ -155,6 +155,68 @@ __global__ __launch_bounds__(256) void nast_lp_logits_bwd_kernel(const float* __
   }
 }
 
+// d % 4 == 0: 16-B accesses (lane = 4 columns, one pass over 256 columns) and 64 sentences per workgroup -- twice the
+// workgroups (T1 x B/128 = 136 leaves half of the CUs idle at B = 512) and four columns per dependent allpos -> KC load chain.
+#define LPLV_BPB 64
+__global__ __launch_bounds__(256) void nast_lp_logits_bwd_vec_kernel(const float* __restrict__ g, const float* __restrict__ qh,
+                                                                     const float* __restrict__ KC, const float* __restrict__ kunk,
+                                                                     const int64_t* __restrict__ allpos, float* __restrict__ dqh,
+                                                                     float* __restrict__ dKC, float* __restrict__ dkunk, int B, int T1,
+                                                                     int NC, int d, float inv) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x;
+  const int b0 = blockIdx.y * LPLV_BPB;
+  for (int c0 = 0; c0 < d; c0 += 256) {
+    const int c = c0 + 4 * lane;
+    float4 s_unk = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < d) {
+      const float4 ku = *reinterpret_cast<const float4*>(kunk + c);
+#pragma unroll 4
+      for (int b = b0 + wave; b < B && b < b0 + LPLV_BPB; b += 4) {
+        const int64_t row = (int64_t)b * T1 + t;
+        const float4 gv = *reinterpret_cast<const float4*>(g + row * 4);
+        float4* dq = reinterpret_cast<float4*>(dqh + row * d + c);
+        if (gv.x == 0.f && gv.y == 0.f && gv.z == 0.f && gv.w == 0.f) {   // positions past the sentence carry no loss
+          *dq = make_float4(0.f, 0.f, 0.f, 0.f);
+          continue;
+        }
+        const int64_t a = allpos[row];
+        const float4 qv = *reinterpret_cast<const float4*>(qh + row * d + c);
+        const float* k1 = KC + ((int64_t)b * NC + a + 1) * d + c;
+        const float4 ka = *reinterpret_cast<const float4*>(k1), kb = *reinterpret_cast<const float4*>(k1 + d),
+                     kc = *reinterpret_cast<const float4*>(k1 + 2 * d);
+        float4 o;
+        o.x = inv * (gv.x * ku.x + gv.y * ka.x + gv.z * kb.x + gv.w * kc.x);
+        o.y = inv * (gv.x * ku.y + gv.y * ka.y + gv.z * kb.y + gv.w * kc.y);
+        o.z = inv * (gv.x * ku.z + gv.y * ka.z + gv.z * kb.z + gv.w * kc.z);
+        o.w = inv * (gv.x * ku.w + gv.y * ka.w + gv.z * kb.w + gv.w * kc.w);
+        *dq = o;
+        s_unk.x = fmaf(gv.x, qv.x, s_unk.x); s_unk.y = fmaf(gv.x, qv.y, s_unk.y);
+        s_unk.z = fmaf(gv.x, qv.z, s_unk.z); s_unk.w = fmaf(gv.x, qv.w, s_unk.w);
+        float* dk1 = dKC + ((int64_t)b * NC + a + 1) * d + c;
+        const float q4[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          atomicAdd(dk1 + e, inv * gv.y * q4[e]);
+          atomicAdd(dk1 + d + e, inv * gv.z * q4[e]);
+          atomicAdd(dk1 + 2 * d + e, inv * gv.w * q4[e]);
+        }
+      }
+    }
+    red[wave][lane] = s_unk;
+    __syncthreads();
+    if (wave == 0 && c < d) {
+      const float4 a = red[0][lane], b4 = red[1][lane], c4 = red[2][lane], e4 = red[3][lane];
+      const float v[4] = {a.x + b4.x + c4.x + e4.x, a.y + b4.y + c4.y + e4.y, a.z + b4.z + c4.z + e4.z, a.w + b4.w + c4.w + e4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[e] != 0.f) atomicAdd(dkunk + c + e, inv * v[e]);
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int nast_lp_logits_fwd_f32(const float* qh, const float* KC, const float* kunk, const int64_t* allpos, float* out,
                                       int B, int T1, int NC, int d, void* stream) {
   NAST_REQUIRE(B >= 0 && T1 >= 1 && NC >= 4 && d >= 1, "nast_lp_logits_fwd_f32: bad sizes");
@@ -172,8 +234,14 @@ extern "C" int nast_lp_logits_bwd_f32(const float* g, const float* qh, const flo
   NAST_REQUIRE(B >= 0 && T1 >= 1 && NC >= 4 && d >= 1, "nast_lp_logits_bwd_f32: bad sizes");
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(g && qh && KC && kunk && allpos && dqh && dKC && dkunk, "nast_lp_logits_bwd_f32: NULL pointer");
-  hipLaunchKernelGGL(nast_lp_logits_bwd_kernel, dim3(T1, (B + LPL_BPB - 1) / LPL_BPB), dim3(256), 0, (hipStream_t)stream, g, qh, KC,
-                     kunk, allpos, dqh, dKC, dkunk, B, T1, NC, d, 1.0f / sqrtf((float)d));
+  const bool vec = (d & 3) == 0 && ((reinterpret_cast<uintptr_t>(qh) | reinterpret_cast<uintptr_t>(KC) | reinterpret_cast<uintptr_t>(kunk) |
+                                     reinterpret_cast<uintptr_t>(dqh) | reinterpret_cast<uintptr_t>(dKC) | reinterpret_cast<uintptr_t>(dkunk)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(nast_lp_logits_bwd_vec_kernel, dim3(T1, (B + LPLV_BPB - 1) / LPLV_BPB), dim3(256), 0, (hipStream_t)stream, g, qh, KC,
+                       kunk, allpos, dqh, dKC, dkunk, B, T1, NC, d, 1.0f / sqrtf((float)d));
+  else
+    hipLaunchKernelGGL(nast_lp_logits_bwd_kernel, dim3(T1, (B + LPL_BPB - 1) / LPL_BPB), dim3(256), 0, (hipStream_t)stream, g, qh, KC,
+                       kunk, allpos, dqh, dKC, dkunk, B, T1, NC, d, 1.0f / sqrtf((float)d));
   NAST_CHECK_LAUNCH("nast_lp_logits_bwd_f32");
   return NAST_OK;
 }

@@ -292,7 +292,8 @@ def _lp_gather_ref(oin, olen, allpos, eos, unk, pos, shift, use_stay):
 
 
 @pytest.mark.parametrize("B,S1,T1,d,shift,use_stay,with_pos", [(5, 7, 6, 32, 0, True, True), (70, 12, 14, 64, 0, True, False),
-                                                               (37, 9, 9, 48, 2, False, True)])
+                                                               (37, 9, 9, 48, 2, False, True), (6, 7, 6, 30, 0, True, True),
+                                                               (200, 33, 34, 256, 0, True, True)])
 def test_lp_gather_fwd_bwd(ops, B, S1, T1, d, shift, use_stay, with_pos):
     g = torch.Generator().manual_seed(B + T1)
     oin = torch.randn(B, S1, d, generator=g)
@@ -315,7 +316,7 @@ def test_lp_gather_fwd_bwd(ops, B, S1, T1, d, shift, use_stay, with_pos):
             relclose(a.grad, b.grad if b.grad is not None else torch.zeros_like(b))
 
 
-@pytest.mark.parametrize("B,T1,S1,d", [(3, 5, 6, 32), (70, 9, 11, 64), (33, 17, 17, 256)])
+@pytest.mark.parametrize("B,T1,S1,d", [(3, 5, 6, 32), (70, 9, 11, 64), (33, 17, 17, 256), (5, 6, 7, 30), (200, 34, 33, 256)])
 def test_lp_skip_logits(ops, B, T1, S1, d):
     """transformer.py:504-507: einsum("bld,bltd->blt", wq(hidden), wk(candidates_output)[allpos]) / sqrt(d)"""
     g = torch.Generator().manual_seed(B * 7 + d)
