@@ -1,6 +1,8 @@
 // LengthPredictor greedy skip decoding, one step (transformer.py:549-567): 4-way skip logits, first-step
 // masking, argmax, position update and the gather of the next decoder input -- one wavefront per sentence,
 // replacing ~15 tiny ATen launches (gather/einsum/linear/max/min/compare) per decoding step.
+#include <stdlib.h>
+
 #include "common.h"
 
 __global__ __launch_bounds__(256) void nast_lp_step_kernel(const float* __restrict__ qh, const float* __restrict__ hid,
@@ -217,6 +219,92 @@ __global__ __launch_bounds__(256) void nast_lp_logits_bwd_vec_kernel(const float
   }
 }
 
+// One workgroup per sentence, no atomics on dKC: the sentence's qh rows, cotangents and allpos are staged in LDS, dqh rows
+// are written as before, and every candidate row p GATHERS its contributions (sum over the positions t with
+// 1 <= p - allpos[t] <= 3, ascending t: deterministic) and is read-modified-written once by the one wavefront that owns it.
+// The atomic versions issue 3 d float atomics per (sentence, position) into lines that are not in L2 (13 M at B = 512,
+// T1 = 34, d = 256: 124 us); dkunk keeps one atomic per column per workgroup.
+__global__ __launch_bounds__(256) void nast_lp_logits_bwd_gather_kernel(const float* __restrict__ g, const float* __restrict__ qh,
+                                                                        const float* __restrict__ KC, const float* __restrict__ kunk,
+                                                                        const int64_t* __restrict__ allpos, float* __restrict__ dqh,
+                                                                        float* __restrict__ dKC, float* __restrict__ dkunk, int B, int T1,
+                                                                        int NC, int d, float inv) {
+  extern __shared__ __attribute__((aligned(16))) float lp_smem[];
+  float* q_s = lp_smem;                          // [T1][d]
+  float* g_s = q_s + (size_t)T1 * d;             // [T1][4]
+  float* red = g_s + (size_t)T1 * 4;             // [4][d]
+  int* a_s = reinterpret_cast<int*>(red + 4 * (size_t)d);   // [T1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  const int d4 = d >> 2;
+  for (int i = threadIdx.x; i < T1 * d4; i += 256)
+    reinterpret_cast<float4*>(q_s)[i] = reinterpret_cast<const float4*>(qh + (int64_t)b * T1 * d)[i];
+  for (int i = threadIdx.x; i < T1; i += 256) {
+    reinterpret_cast<float4*>(g_s)[i] = reinterpret_cast<const float4*>(g + (int64_t)b * T1 * 4)[i];
+    a_s[i] = (int)allpos[(int64_t)b * T1 + i];
+  }
+  __syncthreads();
+  // dqh[t] = inv * (g0 kunk + g1 KC[a+1] + g2 KC[a+2] + g3 KC[a+3]);  dkunk partial = sum_t g0 qh[t]
+  for (int c0 = 0; c0 < d; c0 += 256) {
+    const int c = c0 + 4 * lane;
+    float4 s_unk = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < d) {
+      const float4 ku = *reinterpret_cast<const float4*>(kunk + c);
+      for (int t = wave; t < T1; t += 4) {
+        const float4 gv = *reinterpret_cast<const float4*>(g_s + 4 * t);
+        float4* dq = reinterpret_cast<float4*>(dqh + ((int64_t)b * T1 + t) * d + c);
+        if (gv.x == 0.f && gv.y == 0.f && gv.z == 0.f && gv.w == 0.f) {   // positions past the sentence carry no loss
+          *dq = make_float4(0.f, 0.f, 0.f, 0.f);
+          continue;
+        }
+        const float* k1 = KC + ((int64_t)b * NC + a_s[t] + 1) * d + c;
+        const float4 ka = *reinterpret_cast<const float4*>(k1), kb = *reinterpret_cast<const float4*>(k1 + d),
+                     kc = *reinterpret_cast<const float4*>(k1 + 2 * d);
+        float4 o;
+        o.x = inv * (gv.x * ku.x + gv.y * ka.x + gv.z * kb.x + gv.w * kc.x);
+        o.y = inv * (gv.x * ku.y + gv.y * ka.y + gv.z * kb.y + gv.w * kc.y);
+        o.z = inv * (gv.x * ku.z + gv.y * ka.z + gv.z * kb.z + gv.w * kc.z);
+        o.w = inv * (gv.x * ku.w + gv.y * ka.w + gv.z * kb.w + gv.w * kc.w);
+        *dq = o;
+        const float4 qv = *reinterpret_cast<const float4*>(q_s + (size_t)t * d + c);
+        s_unk.x = fmaf(gv.x, qv.x, s_unk.x); s_unk.y = fmaf(gv.x, qv.y, s_unk.y);
+        s_unk.z = fmaf(gv.x, qv.z, s_unk.z); s_unk.w = fmaf(gv.x, qv.w, s_unk.w);
+      }
+      *reinterpret_cast<float4*>(red + (size_t)wave * d + c) = s_unk;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    const float v = red[c] + red[d + c] + red[2 * (size_t)d + c] + red[3 * (size_t)d + c];
+    if (v != 0.f) atomicAdd(dkunk + c, inv * v);
+  }
+  // dKC[p] += inv * sum_{t : 1 <= p - a[t] <= 3} g[t][p - a[t]] qh[t]
+  for (int p = wave; p < NC; p += 4) {
+    for (int c0 = 0; c0 < d; c0 += 256) {
+      const int c = c0 + 4 * lane;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool any = false;
+      for (int t = 0; t < T1; ++t) {
+        const int j = p - a_s[t];
+        if (j < 1 || j > 3) continue;              // (uniform for the wavefront)
+        const float gj = g_s[4 * t + j];
+        if (gj == 0.f) continue;
+        any = true;
+        if (c < d) {
+          const float4 qv = *reinterpret_cast<const float4*>(q_s + (size_t)t * d + c);
+          acc.x = fmaf(gj, qv.x, acc.x); acc.y = fmaf(gj, qv.y, acc.y); acc.z = fmaf(gj, qv.z, acc.z); acc.w = fmaf(gj, qv.w, acc.w);
+        }
+      }
+      if (any && c < d) {
+        float4* dst = reinterpret_cast<float4*>(dKC + ((int64_t)b * NC + p) * d + c);
+        float4 o = *dst;
+        o.x += inv * acc.x; o.y += inv * acc.y; o.z += inv * acc.z; o.w += inv * acc.w;
+        *dst = o;
+      }
+    }
+  }
+}
+
 extern "C" int nast_lp_logits_fwd_f32(const float* qh, const float* KC, const float* kunk, const int64_t* allpos, float* out,
                                       int B, int T1, int NC, int d, void* stream) {
   NAST_REQUIRE(B >= 0 && T1 >= 1 && NC >= 4 && d >= 1, "nast_lp_logits_fwd_f32: bad sizes");
@@ -236,7 +324,12 @@ extern "C" int nast_lp_logits_bwd_f32(const float* g, const float* qh, const flo
   NAST_REQUIRE(g && qh && KC && kunk && allpos && dqh && dKC && dkunk, "nast_lp_logits_bwd_f32: NULL pointer");
   const bool vec = (d & 3) == 0 && ((reinterpret_cast<uintptr_t>(qh) | reinterpret_cast<uintptr_t>(KC) | reinterpret_cast<uintptr_t>(kunk) |
                                      reinterpret_cast<uintptr_t>(dqh) | reinterpret_cast<uintptr_t>(dKC) | reinterpret_cast<uintptr_t>(dkunk)) & 15) == 0;
-  if (vec)
+  const size_t gather_lds = ((size_t)T1 * d + (size_t)T1 * 4 + 4 * (size_t)d) * sizeof(float) + (size_t)T1 * sizeof(int);
+  static const bool gather_on = [] { const char* e = getenv("NAST_LP_GATHER_BWD"); return e ? atoi(e) != 0 : true; }();   // tuning aid
+  if (vec && gather_on && gather_lds <= 64 * 1024 && (reinterpret_cast<uintptr_t>(g) & 15) == 0)
+    hipLaunchKernelGGL(nast_lp_logits_bwd_gather_kernel, dim3(B), dim3(256), gather_lds, (hipStream_t)stream, g, qh, KC, kunk, allpos, dqh,
+                       dKC, dkunk, B, T1, NC, d, 1.0f / sqrtf((float)d));
+  else if (vec)
     hipLaunchKernelGGL(nast_lp_logits_bwd_vec_kernel, dim3(T1, (B + LPLV_BPB - 1) / LPLV_BPB), dim3(256), 0, (hipStream_t)stream, g, qh, KC,
                        kunk, allpos, dqh, dKC, dkunk, B, T1, NC, d, 1.0f / sqrtf((float)d));
   else
