@@ -210,6 +210,17 @@ int nast_align_lse_bwd_f32(const float* cost0, const float* cost, const int64_t*
                            const float* dvalue, float* dcost0, float* dcost, int B, int T, int S, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Packed-row layout (no counterpart in the reference, which runs every sentence at the padded width): index maps of a
+ * ragged batch in one launch.  lengths int64 [B] (negative counts as 0), width = padded positions per sentence, total =
+ * sum(lengths) as the HOST knows it, rows >= total = allocated packed rows.  Outputs: off int64 [B] / off32 int32 [B]
+ * (exclusive scan), len32 int32 [B], and for packed row r of sentence b at position p: b_of[r] = b, pos[r] = p,
+ * idx[r] = b * width + p (all int64 [total]); idx_p int64 [rows] = idx followed by zeros.  *bad (device int, sticky: the
+ * caller zeroes it once and may share it between calls) is set to 1 and the row maps are zero-filled (in-bounds,
+ * meaningless) when total != sum(lengths).  Limit: B <= 8192.                     */
+int nast_pack_index_i64(const int64_t* lengths, int B, int width, int total, int rows, int64_t* off, int32_t* off32,
+                        int32_t* len32, int64_t* b_of, int64_t* pos, int64_t* idx, int64_t* idx_p, int* bad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * NoiseLayer on the device (noise.py:60-194): blank -> add -> dropout/repeat of
  * NoiseLayer.forward (:60-74) for a whole [S, B] time-major batch of ids, one lane per sentence.  Each stage is
  * skipped when its uniform-draw pointer is NULL.  u_blank [S,B], u_add [M-1,B], new_words int64 [M,B] (the

@@ -6,6 +6,7 @@ There is no CPU / eager fallback: a non-CUDA tensor raises.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -492,6 +493,26 @@ def set_total(lengths, total):
     return lengths
 
 
+NATIVE_PACK_INDEX = os.environ.get("NAST_PACK_TORCH") != "1"      # False: build the index maps with torch ops (what CPU tensors always use)
+_pack_flags = {}              # device -> int32 [1], set by nast_pack_index_i64 when a host-side total was wrong (sticky)
+
+
+def _pack_flag(dev):
+    f = _pack_flags.get(dev)
+    if f is None:
+        f = _pack_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return f
+
+
+def check_packed():
+    """Raise if any packed layout built since the last check was given a row total that disagrees with its lengths (its
+    index maps were zero-filled).  One 4-byte read per device: the training steps call it where they synchronise anyway."""
+    for dev, f in _pack_flags.items():
+        if int(f.item()):
+            f.zero_()
+            raise _lib.NastHipError("PackedSeq: the host-side row total disagrees with the device lengths")
+
+
 class PackedSeq:
     ROW_MULTIPLE = 64        # packed buffers are padded to a multiple of this (weight-gradient GEMMs: K = rows, K % 32 == 0
     #                          keeps them on the fast path).  Padding rows duplicate row 0 on the way in, are kept finite in
@@ -507,6 +528,18 @@ class PackedSeq:
         self.total = total
         self.rows = (total + self.ROW_MULTIPLE - 1) // self.ROW_MULTIPLE * self.ROW_MULTIPLE
         dev = lengths.device
+        self._tail = None
+        if lengths.is_cuda and lengths.dtype == torch.int64 and 1 <= self.B <= 8192 and NATIVE_PACK_INDEX:
+            # one launch instead of ~18 (cumsum, repeat_interleave, arange, gathers, cat): nast_pack_index_i64
+            B, rows = self.B, self.rows
+            i64 = torch.empty(B + 3 * total + rows, dtype=torch.int64, device=dev)
+            i32 = torch.empty(2 * B, dtype=torch.int32, device=dev)
+            self.off, self.b_of, self.pos = i64[:B], i64[B:B + total], i64[B + total:B + 2 * total]
+            self.idx, self.idx_p = i64[B + 2 * total:B + 3 * total], i64[B + 3 * total:]
+            self.off32, self.len32, self.bad = i32[:B], i32[B:], _pack_flag(dev)
+            call("nast_pack_index_i64", _p(_c(lengths)), B, int(width), int(total), int(rows), _p(self.off), _p(self.off32), _p(self.len32),
+                 _p(self.b_of), _p(self.pos), _p(self.idx), _p(self.idx_p), _p(self.bad), _stream())
+            return
         off = torch.cumsum(lengths, 0) - lengths
         self.len32, self.off32 = lengths.to(torch.int32), off.to(torch.int32)
         self.off = off

@@ -262,12 +262,16 @@ class Seq2seq(BaseModel):
     def f_step(self, incoming, temperature, cyc_rec_enable=True, *, use_inference_z):
         """seq2seq.py:416-543 -> (slf, cyc, adv, slf_len, cyc_len, slf_gen_err, cyc_gen_err) as Python floats."""
         with ops.packed_rows(self.pack_rows and incoming.data.sent.numel() >= self.pack_min_tokens):
-            return self._f_step(incoming, temperature, cyc_rec_enable, use_inference_z=use_inference_z)
+            out = self._f_step(incoming, temperature, cyc_rec_enable, use_inference_z=use_inference_z)
+            ops.check_packed()       # (the step has just synchronised for its loss values)
+            return out
 
     def d_step(self, incoming, temperature, *, use_inference_z):
         """seq2seq.py:551-642 -> adv_loss (float)"""
         with ops.packed_rows(self.pack_rows and incoming.data.sent.numel() >= self.pack_min_tokens):
-            return self._d_step(incoming, temperature, use_inference_z=use_inference_z)
+            out = self._d_step(incoming, temperature, use_inference_z=use_inference_z)
+            ops.check_packed()
+            return out
 
     def _f_step(self, incoming, temperature, cyc_rec_enable=True, *, use_inference_z):
         self.net.model_D.eval()

@@ -478,3 +478,42 @@ def test_attention_packed_rows_causal(ops):
     relclose(ops.unpack_rows(dq, ps), qr.grad * live)
     relclose(ops.unpack_rows(dk_, ps), kr.grad * live)
     relclose(ops.unpack_rows(dv, ps), vr.grad * live)
+
+
+@pytest.mark.parametrize("B,width,zero_frac", [(1, 5, 0.0), (7, 9, 0.3), (513, 33, 0.0), (2048, 17, 0.1), (64, 64, 0.0)])
+def test_pack_index_kernel_equals_torch_maps(ops, B, width, zero_frac):
+    """nast_pack_index_i64 (one launch) against the torch formulation of ops.PackedSeq -- integer maps, bit-exact."""
+    g = torch.Generator().manual_seed(B * 31 + width)
+    lengths = torch.randint(1, width + 1, (B,), generator=g)
+    lengths[torch.rand(B, generator=g) < zero_frac] = 0          # (the tail layout of one-word sentences has zero lengths)
+    lengths = lengths.cuda()
+    total = int(lengths.sum())
+    nat = ops.PackedSeq(lengths, width, total)
+    assert hasattr(nat, "bad")
+    ops.check_packed()                                           # (does not raise)
+    ops.NATIVE_PACK_INDEX = False
+    try:
+        ref = ops.PackedSeq(lengths, width, total)
+    finally:
+        ops.NATIVE_PACK_INDEX = True
+    assert not hasattr(ref, "bad")
+    assert nat.rows == ref.rows and nat.total == ref.total
+    for name in ("off", "off32", "len32", "b_of", "pos", "idx", "idx_p"):
+        a, b = getattr(nat, name), getattr(ref, name)
+        assert a.dtype == b.dtype and a.shape == b.shape, name
+        assert torch.equal(a, b), name
+    if B > 1 and zero_frac == 0.0:         # tail() describes lengths - 1: every sentence needs a first row
+        t_nat = nat.tail()
+        ops.NATIVE_PACK_INDEX = False
+        try:
+            t_ref = ref.tail()
+        finally:
+            ops.NATIVE_PACK_INDEX = True
+        assert torch.equal(t_nat[0], t_ref[0]) and torch.equal(t_nat[1].idx_p, t_ref[1].idx_p)
+    # a wrong host-side total is reported, not silently used
+    from nast_amd import _lib
+    wrong = ops.PackedSeq(lengths, width, total + 64)
+    assert int(wrong.idx_p.abs().max().item()) == 0              # zero-filled, in bounds
+    with pytest.raises(_lib.NastHipError):
+        ops.check_packed()
+    ops.check_packed()                                           # the flag was reset
