@@ -159,6 +159,8 @@ def main():
     cfg = dict(V=9600, d=256, h=4, N=4, L=L, learnable=learnable)
     B = a.batch_per_gpu
     model = build_model(cfg, "cuda")
+    if os.environ.get("NAST_PACK_MIN"):               # A/B aid: token count from which the packed-row execution is used
+        model.pack_min_tokens = int(os.environ["NAST_PACK_MIN"])
     if os.environ.get("NAST_NOISE_HOST") == "1":      # A/B aid: the host (numpy) NoiseLayer instead of the device kernel
         model.net.noiseLayer.device_side = False
     from nast_amd import ops as _ops
