@@ -80,7 +80,8 @@ int nast_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta
 /* dx is [rows_in, d] and is fully written (rows not selected by the map get 0);
  * dx_add (may be NULL, only with grp == 0): dx = LN-gradient + dx_add  (the residual branch of
  * SublayerConnection, transformer.py:326, fused so that no separate add kernel runs);
- * dgamma/dbeta [d] are ACCUMULATED (+=, fp32 atomics) -- caller zero-initialises or passes .grad. */
+ * dgamma/dbeta [d] are ACCUMULATED (+=, fp32 atomics) -- caller zero-initialises or passes .grad; either may be
+ * NULL (frozen parameter): that sum is skipped. */
 int nast_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
                            const float* rstd, float* dx, float* dgamma, float* dbeta, const float* dx_add,
                            int rows_out, int rows_in, int d,

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void nast_ln_bwd_kernel(const float* __restric
   }
   __syncthreads();
   for (int c = threadIdx.x; c < d; c += 256) {
-    atomicAdd(dgamma + c, rg[c] + rg[d + c] + rg[2 * d + c] + rg[3 * d + c]);
-    atomicAdd(dbeta + c, rb[c] + rb[d + c] + rb[2 * d + c] + rb[3 * d + c]);
+    if (dgamma) atomicAdd(dgamma + c, rg[c] + rg[d + c] + rg[2 * d + c] + rg[3 * d + c]);   // (NULL: frozen parameter)
+    if (dbeta) atomicAdd(dbeta + c, rb[c] + rb[d + c] + rb[2 * d + c] + rb[3 * d + c]);
   }
 }
 
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(1024) void nast_ln_bwd_vec_kernel(const float* __re
       sg += rg[w * d + c];
       sb += rb[w * d + c];
     }
-    atomicAdd(dgamma + c, sg);
-    atomicAdd(dbeta + c, sb);
+    if (dgamma) atomicAdd(dgamma + c, sg);     // (NULL: frozen parameter)
+    if (dbeta) atomicAdd(dbeta + c, sb);
   }
 }
 
@@ -271,7 +271,7 @@ extern "C" int nast_layernorm_bwd_f32(const float* dy, const float* x, const flo
   NAST_REQUIRE(d >= 1 && d <= 64 * LN_MAX_PER_LANE, "nast_layernorm_bwd_f32: d=%d unsupported", d);
   NAST_REQUIRE(rows_out >= 0 && rows_in >= rows_out, "nast_layernorm_bwd_f32: bad row counts %d/%d", rows_out, rows_in);
   if (rows_in == 0) return NAST_OK;
-  NAST_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "nast_layernorm_bwd_f32: NULL pointer");
+  NAST_REQUIRE(dy && x && gamma && mean && rstd && dx, "nast_layernorm_bwd_f32: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
   if (grp > 0) {
     if (hipMemsetAsync(dx, 0, (size_t)rows_in * d * sizeof(float), s) != hipSuccess) {

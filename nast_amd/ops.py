@@ -404,12 +404,9 @@ class LayerNormFn(torch.autograd.Function):
 
 
 def ln_param_buffers(gamma, beta, like):
-    """The LayerNorm backward kernel always accumulates both parameter gradients: frozen parameters get scratch."""
-    bufs, rets = grad_buffers([gamma, beta])
-    for i in range(2):
-        if bufs[i] is None:
-            bufs[i] = torch.zeros_like(like)
-    return bufs, rets
+    """Buffers the LayerNorm backward kernel accumulates the parameter gradients into (None = frozen parameter: the
+    kernel takes NULL and skips that sum)."""
+    return grad_buffers([gamma, beta])
 
 
 def layer_norm(x, gamma, beta):
