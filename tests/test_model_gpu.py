@@ -398,3 +398,13 @@ def test_transfer_matches_golden_generate():
         assert np.array_equal(pos, g["out/generate/allpos"][b][1:glen[b] + 1])
     assert abs(out.length_delta - float(np.mean(glen - g["in/gold_len"]))) < 1e-6
     assert model.net.model_F.training
+
+
+def test_reserved_second_stream_is_the_one_the_steps_use():
+    """seq2seq.reserve_streams() (to be called before init_process_group) hands the trainer its stream."""
+    from nast_amd import seq2seq, ops
+    s = seq2seq.reserve_streams()
+    assert seq2seq.reserve_streams() is s and isinstance(s, torch.cuda.Stream)
+    model = seq2seq.Seq2seq(make_param(device="cuda", V=40, d=32, h=2, N=1, L=8, learnable=True))
+    assert model._side_stream(torch.device("cuda", torch.cuda.current_device())) is s
+    assert s in ops.peer_streams and torch.cuda.current_stream() in ops.peer_streams
