@@ -628,14 +628,102 @@ def case_misc(ref_utils, ref_s2s, out_dir):
     save(out_dir, "g10_misc", g)
 
 
+class DrawRecorder:
+    """Records what np.random.rand / np.random.randint / torch.multinomial hand to the reference's NoiseLayer."""
+
+    def __init__(self):
+        self.rand, self.randint, self.multinomial = [], [], []
+
+    def __enter__(self):
+        self._o = (np.random.rand, np.random.randint, torch.multinomial)
+        rec = self
+
+        def rand(*shape):
+            r = rec._o[0](*shape)
+            rec.rand.append(np.array(r, copy=True))
+            return r
+
+        def randint(lo, hi=None, *a, **k):
+            r = rec._o[1](lo, hi, *a, **k)
+            rec.randint.append((int(lo), int(hi), int(r)))
+            return r
+
+        def multinomial(*a, **k):
+            r = rec._o[2](*a, **k)
+            rec.multinomial.append(r.detach().clone())
+            return r
+
+        np.random.rand, np.random.randint, torch.multinomial = rand, randint, multinomial
+        return self
+
+    def __exit__(self, *exc):
+        np.random.rand, np.random.randint, torch.multinomial = self._o
+
+
+def case_noise(ref_utils, out_dir):
+    """G11: the three stages of the reference's NoiseLayer.forward that the run configuration uses (noise.py:60-74:
+    word_blank :103-135, word_add :76-101, word_dropout :137-194), each with the uniform draws / multinomial candidates /
+    randint picks it consumed captured next to its input and output."""
+    import noise as ref_noise                     # /root/reference/styletransformer/noise.py
+    g = {}
+    cases = [("run", dict(blank=0.1, drop=0.05, rep=0.0, add=1 / 0.95 - 1, L=16, V=60, B=37)),      # run.py:90-95
+             ("heavy", dict(blank=0.5, drop=0.6, rep=0.3, add=0.5, L=12, V=40, B=70)),
+             ("alldrop", dict(blank=0.3, drop=0.93, rep=0.0, add=0.3, L=8, V=30, B=33)),           # most sentences lose every word
+             ("narrow", dict(blank=0.2, drop=0.3, rep=0.4, add=0.6, L=14, V=30, B=20, S=9))]        # input narrower than max_length
+    names = []
+    for ci, (tag, c) in enumerate(cases):
+        rng = np.random.default_rng(300 + ci)
+        np.random.seed(300 + ci)
+        torch.manual_seed(300 + ci)
+        L, V, B = c["L"], c["V"], c["B"]
+        S = c.get("S", L)
+        nl = ref_noise.NoiseLayer(c["blank"], c["drop"], 0, c["rep"], c["add"], keep_go=False, max_length=L, dm=FakeDM(V, rng, L))
+        for trial in range(3):
+            name = f"{tag}{trial}"
+            names.append(name)
+            sent, slen = synth_batch(rng, B, S, V, full_first=(trial != 1))
+            if trial == 2:                        # a few one-word sentences
+                sent[:5, 1] = 2
+                sent[:5, 2:] = 0
+                slen[:5] = 2
+            words = sent.t().contiguous()
+            rev = torch.tensor(rng.integers(0, 2, size=B))
+            l0 = slen.numpy()
+            p = f"{name}/"
+            for k in ("blank", "drop", "rep", "add", "L", "V", "B"):
+                g[p + "cfg/" + k] = np.asarray(c[k])
+            g[p + "in/x"], g[p + "in/l"], g[p + "in/rev_domain"] = np_(words), np.asarray(l0), np_(rev)
+            with DrawRecorder() as r:
+                x1, l1 = nl.word_blank(words, l0)
+            g[p + "blank/u"] = r.rand[0]
+            g[p + "blank/x"], g[p + "blank/l"] = np_(x1), np.asarray(l1)
+            with DrawRecorder() as r:
+                x2, l2 = nl.word_add(x1, l1, rev)
+            g[p + "add/u"] = r.rand[0]
+            g[p + "add/new_words"] = np_(r.multinomial[0].transpose(0, 1))            # [M, B] as the reference uses them
+            g[p + "add/x"], g[p + "add/l"] = np_(x2), np.asarray(l2)
+            with DrawRecorder() as r:
+                x3, l3 = nl.word_dropout(x2, l2)
+            g[p + "drop/u_keep"], g[p + "drop/u_rep"] = r.rand[0], r.rand[1]
+            g[p + "drop/picks"] = np.asarray(r.randint, dtype=np.int64).reshape(-1, 3)   # (lo, hi, result) per all-dropped sentence, batch order
+            g[p + "drop/x"], g[p + "drop/l"] = np_(x3), np.asarray(l3, dtype=np.int64)
+    g["names"] = np.asarray(names)
+    g["cnt_check/p"] = np_(nl.cnt)
+    save(out_dir, "g11_noise_stages", g)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+    ap.add_argument("--only", default=None, help="generate one case only (noise)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(1)  # deterministic summation order
     ref_utils, ref_tf, ref_s2s = import_reference()
     print("reference imported; generating goldens ...")
+    if a.only == "noise":
+        case_noise(ref_utils, a.out)
+        return
     case_layers(ref_tf, a.out)
     case_style_transformer(ref_utils, ref_tf, a.out)
     case_match(ref_utils, ref_tf, a.out)
@@ -643,6 +731,7 @@ def main():
     case_discriminator(ref_utils, ref_tf, a.out)
     case_steps(ref_utils, ref_tf, ref_s2s, a.out)
     case_misc(ref_utils, ref_s2s, a.out)
+    case_noise(ref_utils, a.out)
     print("done")
 
 

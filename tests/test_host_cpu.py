@@ -124,6 +124,44 @@ def test_noise_stages_known_answers():
     assert out[:, 0].tolist() == [11, 2]
 
 
+def _noise_cases():
+    g = load_golden("g11_noise_stages")
+    for name in g["names"].tolist():
+        c = sub(g, name + "/")
+        yield name, c
+
+
+def test_noise_stages_match_reference_captures():
+    """blank_apply / add_apply / dropout_apply against per-stage captures of the reference's word_blank / word_add /
+    word_dropout (noise.py:103-135, :76-101, :137-194; oracle/gen_golden.py::case_noise recorded the np.random.rand /
+    torch.multinomial / np.random.randint values each stage consumed): same draws in, same ids and lengths out."""
+    from nast_amd.noise import NoiseLayer
+    n = 0
+    for name, c in _noise_cases():
+        L, V = int(c["cfg/L"]), int(c["cfg/V"])
+        nl = NoiseLayer(float(c["cfg/blank"]), float(c["cfg/drop"]), 0, float(c["cfg/rep"]), float(c["cfg/add"]), keep_go=False,
+                        max_length=L, dm=FakeDM(V, L))
+        x, l = c["in/x"], c["in/l"].astype(np.int64)
+        x1, l1 = nl.blank_apply(x, l, c["blank/u"])
+        assert np.array_equal(x1, c["blank/x"]) and np.array_equal(l1, c["blank/l"]), name
+        x2, l2 = nl.add_apply(c["blank/x"], c["blank/l"].astype(np.int64), c["add/u"], c["add/new_words"])
+        assert np.array_equal(l2, c["add/l"]), name
+        assert np.array_equal(x2, c["add/x"]), name
+        picks = iter(c["drop/picks"].reshape(-1, 3).tolist())
+
+        def pick(nwords):
+            lo, hi, r = next(picks)
+            assert (lo, hi) == (0, nwords)            # the reference asked for the same range
+            return r
+
+        x3, l3 = nl.dropout_apply(c["add/x"], c["add/l"].astype(np.int64), c["drop/u_keep"], c["drop/u_rep"], pick)
+        assert np.array_equal(l3, c["drop/l"]), name
+        assert np.array_equal(x3, c["drop/x"]), name
+        assert next(picks, None) is None
+        n += 1
+    assert n == 12
+
+
 def test_preprocess_batch_and_temperature():
     from nast_amd.seq2seq import Seq2seq
     s = Seq2seq.__new__(Seq2seq)

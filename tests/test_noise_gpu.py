@@ -70,6 +70,60 @@ def test_device_noise_equals_host_stages(B, L, S, probs):
         assert (got[want_x.shape[0]:] == nl.pad_index).all()
 
 
+def test_device_noise_matches_reference_captures():
+    """nast_noise_i64 against the per-stage captures of the REFERENCE's NoiseLayer (tests/golden/g11_noise_stages.npz,
+    written by oracle/gen_golden.py::case_noise from noise.py:76-194 with its rand / multinomial / randint values
+    recorded): each stage alone on the reference's stage input, and the three stages chained in one launch.  Bit-exact."""
+    from conftest import load_golden, sub
+    from nast_amd import ops
+    g = load_golden("g11_noise_stages")
+    C = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for name in g["names"].tolist():
+        c = sub(g, name + "/")
+        L, B = int(c["cfg/L"]), int(c["cfg/B"])
+        probs = dict(blank_prob=float(c["cfg/blank"]), add_prob=float(c["cfg/add"]), dropout_prob=float(c["cfg/drop"]),
+                     repeat_prob=float(c["cfg/rep"]))
+        ids = dict(pad=0, unk=3, eos=2)
+        # the reference picks a survivor with np.random.randint(0, n) for the sentences that lost every word (noise.py:179), in
+        # batch order; the kernel takes floor(u * n) from a per-sentence uniform: u = (r + 0.5) / n reproduces pick r
+        xa, la = c["add/x"], c["add/l"].astype(np.int64)
+        nwords = np.where(xa[la - 1, np.arange(B)] == 2, la - 1, la)
+        keep = c["drop/u_keep"] >= probs["dropout_prob"]
+        km = keep[:xa.shape[0]] & (np.arange(xa.shape[0])[:, None] < nwords[None, :])
+        empty = np.nonzero(km.sum(0) == 0)[0]
+        picks = c["drop/picks"].reshape(-1, 3)
+        assert len(empty) == len(picks) and np.array_equal(picks[:, 1], nwords[empty])
+        u_pick = np.full(B, 0.5)
+        u_pick[empty] = (picks[:, 2] + 0.5) / picks[:, 1]
+
+        def run(x, l, **kw):
+            out, out_len = ops.noise_tokens(C(x), C(l.astype(np.int64)), L, **ids, **kw)
+            return out.cpu().numpy(), out_len.cpu().numpy()
+
+        def same(got, want_x, want_l, what):
+            gx, gl = got
+            assert np.array_equal(gl, want_l), (name, what)
+            w = want_x.shape[0]
+            # before the dropout stage rows past a sentence's new length are not defined by the kernel's contract
+            live = np.arange(w)[:, None] < want_l[None, :]
+            assert np.array_equal(np.where(live, gx[:w], 0), np.where(live, want_x, 0)), (name, what)
+
+        same(run(c["in/x"], c["in/l"], u_blank=C(c["blank/u"]), blank_prob=probs["blank_prob"]), c["blank/x"], c["blank/l"], "blank")
+        same(run(c["blank/x"], c["blank/l"], u_add=C(c["add/u"]), new_words=C(c["add/new_words"]), add_prob=probs["add_prob"]),
+             c["add/x"], c["add/l"], "add")
+        drop = dict(u_keep=C(c["drop/u_keep"]), u_rep=C(c["drop/u_rep"]), u_pick=C(u_pick), dropout_prob=probs["dropout_prob"],
+                    repeat_prob=probs["repeat_prob"])
+        gx, gl = run(xa, la, **drop)
+        assert np.array_equal(gl, c["drop/l"]), (name, "dropout")
+        w = c["drop/x"].shape[0]
+        assert np.array_equal(gx[:w], c["drop/x"]) and (gx[w:] == 0).all(), (name, "dropout")
+        # the whole chain in one launch, as NoiseLayer.forward issues it
+        gx, gl = run(c["in/x"], c["in/l"], u_blank=C(c["blank/u"]), blank_prob=probs["blank_prob"], u_add=C(c["add/u"]),
+                     new_words=C(c["add/new_words"]), add_prob=probs["add_prob"], **drop)
+        assert np.array_equal(gl, c["drop/l"]), (name, "chain")
+        assert np.array_equal(gx[:w], c["drop/x"]) and (gx[w:] == 0).all(), (name, "chain")
+
+
 def test_noise_layer_device_path_invariants():
     """NoiseLayer.forward on CUDA tensors takes the device path; outputs keep the reference's invariants."""
     from nast_amd.noise import NoiseLayer
