@@ -90,20 +90,24 @@ class FusedAdam(optim.Adam):
                     _, ptrs, sizes, _, (ct, co, nc) = t
                     ops.call("nast_multi_sqnorm_f32", ptrs[1].data_ptr(), sizes.data_ptr(), sizes.numel(), sq.data_ptr(),
                              ct.data_ptr(), co.data_ptr(), nc, self.CHUNK, stream)
-        for g, pl, t in zip(self.param_groups, plists, tabs):
+        for gi, (g, pl, t) in enumerate(zip(self.param_groups, plists, tabs)):
             if t is None:
                 continue
-            steps = {float(self.state[p]["step"]) for p in pl}
-            if len(steps) != 1:
-                raise NotImplementedError("FusedAdam: parameters of one group must share their step count")
-            step = steps.pop() + 1
+            # torch.optim.Adam keeps one step count per parameter (a parameter that gets its first gradient late -- e.g. the
+            # length predictor while `pre_z_batch` steps run without it, seq2seq.py:241-247 -- has a smaller one, and so have
+            # restored states): one launch per distinct count, each with its own bias corrections.  Normally there is one.
+            by_step = {}
             for p in pl:
-                self.state[p]["step"] += 1
-            b1, b2 = g["betas"]
-            _, ptrs, sizes, _, (ct, co, nc) = t
-            ops.call("nast_multi_adam_f32", ptrs[0].data_ptr(), ptrs[1].data_ptr(), ptrs[2].data_ptr(), ptrs[3].data_ptr(),
-                     sizes.data_ptr(), sizes.numel(), sq.data_ptr() if sq is not None else None,
-                     float(max_norm) if max_norm is not None else 0.0, float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-                     float(g["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, ct.data_ptr(), co.data_ptr(), nc, self.CHUNK,
-                     stream)
+                by_step.setdefault(float(self.state[p]["step"]), []).append(p)
+            for si, (step0, sub) in enumerate(sorted(by_step.items())):
+                step = step0 + 1
+                for p in sub:
+                    self.state[p]["step"] += 1
+                b1, b2 = g["betas"]
+                _, ptrs, sizes, _, (ct, co, nc) = t if len(by_step) == 1 else self._table((gi, "step", si), g, sub)
+                ops.call("nast_multi_adam_f32", ptrs[0].data_ptr(), ptrs[1].data_ptr(), ptrs[2].data_ptr(), ptrs[3].data_ptr(),
+                         sizes.data_ptr(), sizes.numel(), sq.data_ptr() if sq is not None else None,
+                         float(max_norm) if max_norm is not None else 0.0, float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                         float(g["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, ct.data_ptr(), co.data_ptr(), nc, self.CHUNK,
+                         stream)
         return sq.sqrt().reshape(()) if sq is not None else None

@@ -325,9 +325,29 @@ def test_training_steps_golden(tag, mode, two_streams):
                 np.testing.assert_allclose(w, v, rtol=1e-6, atol=1e-7, err_msg=k)
 
 
-def _oracle_vs_hip_step(cfg, B, seed=0):
-    """One learnable f_step on fresh weights: HIP path vs the CPU oracle on identical weights, batch and Gumbel draw."""
+def _tensor_class(name):
+    if "length_predictor" in name:
+        return "length_predictor"
+    if "generator" in name:
+        return "generator"
+    if "embed" in name:
+        return "embeddings"
+    if "norm" in name:
+        return "layer_norm"
+    if name.endswith(".bias"):
+        return "biases"
+    if "pw_ffn" in name:
+        return "ffn_weights"
+    return "attention_weights"
+
+
+def _oracle_vs_hip_step(cfg, B, seed=0, precision="fp32", name=None):
+    """One learnable f_step on fresh weights: HIP path vs the CPU oracle on identical weights, batch and Gumbel draw.
+    Returns a report: the 7 returned losses and the pre-clip gradient norm of both sides, and per tensor class the largest
+    error of the (clipped) parameter gradients and of the post-Adam weights.  Written to gpurun_out/parity_<name>.json."""
+    import json, os
     import nast_amd.utils as U
+    from nast_amd import ops
     from nast_amd.seq2seq import Seq2seq
     from nast_amd.utils import Storage
     from oracle import nast_oracle as O
@@ -354,24 +374,100 @@ def _oracle_vs_hip_step(cfg, B, seed=0):
         gen_lp = O.style_transformer(tr.w, tr.cfg, sent, slen, None, None, 1 - dom, True, 1.0, True)[0]
     E = torch.empty_like(gen_lp).exponential_(generator=gen)
     ref = tr.f_step(sent, slen, dom, sent, slen, [E])
-    with U.inject_noise([E.cuda()]):
+    with U.inject_noise([E.cuda()]), ops.gemm_precision(precision):
         got = model.f_step(inc, 1.0, use_inference_z=True)
-    return np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64), float(model.last_grad_norm), float(tr.last_norm)
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    rep = {"cfg": {k: (int(v) if not isinstance(v, bool) else v) for k, v in cfg.items()}, "B": B, "precision": precision,
+           "losses_hip": got.tolist(), "losses_oracle": ref.tolist(),
+           "loss_rel_err": float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30) * (np.abs(ref) > 0))),
+           "grad_norm_hip": float(model.last_grad_norm), "grad_norm_oracle": float(tr.last_norm)}
+    rep["grad_norm_rel_err"] = abs(rep["grad_norm_hip"] - rep["grad_norm_oracle"]) / rep["grad_norm_oracle"]
+    named = dict(model.net.named_parameters())
+    gref = {k: v for k, v in tr.last_grads.items() if v is not None}
+    gmax = max(float(v.abs().max()) for v in gref.values())
+    lr = cfg.get("lr_F", 1e-4)
+    classes = {}
+    for k, gr in gref.items():
+        p = named[k]
+        assert p.grad is not None, k
+        gg = p.grad.detach().cpu()
+        c = classes.setdefault(_tensor_class(k), {"tensors": 0, "grad_err_vs_tensor_max": 0.0, "grad_err_vs_model_max": 0.0,
+                                                   "weight_err_vs_tensor_max": 0.0, "weight_err_solid_vs_tensor_max": 0.0,
+                                                   "weight_err_in_adam_steps": 0.0, "worst": ""})
+        err = float((gg - gr).abs().max())
+        tscale = max(float(gr.abs().max()), 1e-3 * gmax)       # floor: 1e-4 of it is 1e-7 of the model's largest gradient (fp32 epsilon)
+        if err / tscale > c["grad_err_vs_tensor_max"]:
+            c["grad_err_vs_tensor_max"], c["worst"] = err / tscale, k
+        c["grad_err_vs_model_max"] = max(c["grad_err_vs_model_max"], err / gmax)
+        w, wr = p.detach().cpu(), tr.w[k].detach()
+        werr = (w - wr).abs()
+        wmax = float(wr.abs().max()) + 1e-30
+        c["weight_err_vs_tensor_max"] = max(c["weight_err_vs_tensor_max"], float(werr.max()) / wmax)
+        c["weight_err_in_adam_steps"] = max(c["weight_err_in_adam_steps"], float(werr.max()) / lr)
+        solid = gr.abs() > 1e-3 * gmax          # Adam's first step is -lr * g / (|g| + eps): ill-conditioned where |g| ~ rounding noise
+        if bool(solid.any()):
+            c["weight_err_solid_vs_tensor_max"] = max(c["weight_err_solid_vs_tensor_max"], float(werr[solid].max()) / wmax)
+        c["tensors"] += 1
+    for k, p in named.items():
+        if k.startswith("model_F.") and k not in gref:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{k} has a gradient the oracle lacks"
+    rep["classes"] = classes
+    rep["grad_err_vs_tensor_max"] = max(c["grad_err_vs_tensor_max"] for c in classes.values())
+    rep["weight_err_solid_vs_tensor_max"] = max(c["weight_err_solid_vs_tensor_max"] for c in classes.values())
+    rep["weight_err_in_adam_steps"] = max(c["weight_err_in_adam_steps"] for c in classes.values())
+    if name:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, f"parity_{name}.json"), "w") as f:
+            json.dump(rep, f, indent=1)
+        print(f"\n[parity {name}] loss {rep['loss_rel_err']:.2e}  grad-norm {rep['grad_norm_rel_err']:.2e}  "
+              f"grads {rep['grad_err_vs_tensor_max']:.2e}  weights(solid) {rep['weight_err_solid_vs_tensor_max']:.2e}  "
+              f"weights(all, in Adam steps) {rep['weight_err_in_adam_steps']:.2f}")
+        for cn, c in sorted(classes.items()):
+            print(f"   {cn:18s} n={c['tensors']:3d} grad/tensor {c['grad_err_vs_tensor_max']:.2e} grad/model {c['grad_err_vs_model_max']:.2e} "
+                  f"w {c['weight_err_vs_tensor_max']:.2e} w(solid) {c['weight_err_solid_vs_tensor_max']:.2e}  worst {c['worst']}")
+    return rep
 
 
-def test_stress_shape_step_vs_oracle():
-    """BASELINE.json configs[4] shape at reduced depth/batch: d=1024, 16 heads, L=128 (129-token attention: the LDS
-    kernels), V=32000, 4d=4096 FFN -- every kernel family beyond its d=256 / L<=32 tuning point, fp32, 1e-3 on the losses."""
-    got, ref, gn, gn_ref = _oracle_vs_hip_step(dict(V=32000, d=1024, h=16, N=2, L=128, learnable=True), B=2)
-    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(gn, gn_ref, rtol=1e-3)
+def _assert_step_parity(rep, tol):
+    """north_star: fp32 losses and gradients within 1e-4 relative (bf16 variant 2e-2).  Gradients: every parameter tensor,
+    error relative to that tensor's largest gradient (floored at 1e-3 of the model's largest: analytically-zero gradients
+    such as the key biases have no scale of their own).  Post-Adam weights: relative to the tensor's largest weight on the
+    elements whose gradient is above rounding noise; everywhere else the update is bounded by Adam's step (2 lr)."""
+    assert rep["loss_rel_err"] <= tol, rep
+    assert rep["grad_norm_rel_err"] <= tol, rep
+    assert rep["grad_err_vs_tensor_max"] <= tol, {k: (c["grad_err_vs_tensor_max"], c["worst"]) for k, c in rep["classes"].items()}
+    assert rep["weight_err_solid_vs_tensor_max"] <= tol, rep["classes"]
+    assert rep["weight_err_in_adam_steps"] <= 2.0 + 1e-3, rep["classes"]
+
+
+BENCH_CFG = dict(V=9600, d=256, h=4, N=4, L=32, learnable=True)
 
 
 def test_bench_shape_step_vs_oracle():
-    """The benchmark model (d=256, h=4, 4 layers, L=32, V=9600) at a small batch against the oracle."""
-    got, ref, gn, gn_ref = _oracle_vs_hip_step(dict(V=9600, d=256, h=4, N=4, L=32, learnable=True), B=6)
-    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(gn, gn_ref, rtol=1e-3)
+    """The benchmark model (d=256, h=4, 4 layers, L=32, V=9600) at a small batch against the oracle: losses, gradient norm,
+    EVERY parameter gradient and the post-Adam weights at north_star's 1e-4."""
+    _assert_step_parity(_oracle_vs_hip_step(BENCH_CFG, B=6, name="bench_b6"), 1e-4)
+
+
+def test_bench_shape_step_vs_oracle_full_batch():
+    """The same at the benchmarked batch: 512 sentences (two streams, packed rows, split-K weight gradients with K = all rows)."""
+    _assert_step_parity(_oracle_vs_hip_step(BENCH_CFG, B=512, seed=3, name="bench_b512"), 1e-4)
+
+
+def test_stress_shape_step_vs_oracle():
+    """BASELINE.json configs[4] shape at reduced depth/batch: d=1024, 16 heads, L=128 (129-token attention), V=32000,
+    4d=4096 FFN -- every kernel family beyond its d=256 / L<=32 tuning point, fp32."""
+    _assert_step_parity(_oracle_vs_hip_step(dict(V=32000, d=1024, h=16, N=2, L=128, learnable=True), B=2, name="stress_n2_fp32"), 1e-4)
+
+
+def test_stress_shape_full_depth_bf16_vs_oracle():
+    """BASELINE.json configs[4] at its real depth and precision: d=1024, 16 heads, 8 layers, L=128, V=32000, bf16-MFMA GEMMs
+    (fp32 accumulate; LayerNorm / softmax / alignment fp32), small batch, against the fp32 oracle at north_star's 2e-2."""
+    rep = _oracle_vs_hip_step(dict(V=32000, d=1024, h=16, N=8, L=128, learnable=True), B=2, seed=5, precision="bf16", name="stress_n8_bf16")
+    assert rep["loss_rel_err"] <= 2e-2 and rep["grad_norm_rel_err"] <= 2e-2, rep
+    # gradients of the bf16 variant: relative to the model's largest gradient (rounding of every operand to 8 bits)
+    assert max(c["grad_err_vs_model_max"] for c in rep["classes"].values()) <= 2e-2, rep["classes"]
 
 
 def test_transfer_matches_golden_generate():
