@@ -307,6 +307,18 @@ int64_t nast_lp_decode_workspace_bytes(int B, int S1, int d, int dff, int L, int
  * *steps_out < 0: no read-back, all L steps are enqueued and the call returns at once (steps = L). */
 int nast_lp_decode_f32(const nast_lp_decode_args* args, int* steps_out, void* stream);
 
+/* Allocation-free variant of nast_lp_decode_f32.  NO counterpart in the reference: it exists for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
+ * arguments and results, but args->workspace is IGNORED (may be NULL): the workspace lives in a device array built into the
+ * library, NAST_LP_DECODE_STATIC_BYTES per GPU (each GPU the library runs on holds its copy until the process ends).
+ * A decode that needs more (nast_lp_decode_workspace_bytes() > NAST_LP_DECODE_STATIC_BYTES) is rejected with NAST_EINVAL and
+ * a message; 64 MiB covers 128 sentences at S1 = 33, d = 256, L = 32, 3 layers.  The call makes no hipMalloc / hipFree and no
+ * other allocation.  Every call on a GPU shares that GPU's buffer (it keeps the last call's contents; every word a
+ * kernel reads is rewritten by the call itself first): calls that overlap on one GPU -- two streams, two threads -- RACE;
+ * serialise them, or use nast_lp_decode_f32 with one workspace per concurrent call. */
+#define NAST_LP_DECODE_STATIC_BYTES (64u << 20)
+int nast_lp_decode_static_f32(const nast_lp_decode_args* args, int* steps_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser side (seq2seq.py:536-537, :637-638): multi-tensor L2 norm + clip + Adam in few launches.
  * ptrs are device arrays of device pointers (one entry per parameter tensor), sizes int64 element counts.

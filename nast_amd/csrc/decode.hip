@@ -1,8 +1,6 @@
 // Greedy skip decoding of the LengthPredictor (transformer.py:525-570) driven from native code: ~26 kernel
 // launches per step are enqueued back to back from C++ (no interpreter in the loop), with a real K/V cache
 // instead of the reference's per-step re-projection of the whole prefix.
-#include <vector>
-
 #include "common.h"
 
 namespace {
@@ -100,8 +98,10 @@ extern "C" int64_t nast_lp_decode_workspace_bytes(int B, int S1, int d, int dff,
     if (rc_ != 0) return rc_; \
   } while (0)
 
-extern "C" int nast_lp_decode_f32(const nast_lp_decode_args* A, int* steps_out, void* stream_) {
-  hipStream_t s = (hipStream_t)stream_;
+// The decode itself; `workspace` is nast_lp_decode_workspace_bytes() bytes of device memory, 256-B aligned.  Every word of
+// it that a kernel reads is written earlier in the same call (candidate tables, K/V caches up to the current step, the
+// position / progress counters by lp_init_kernel), so nothing has to start at zero.
+static int lp_decode_impl(const nast_lp_decode_args* A, float* workspace, int* steps_out, hipStream_t s) {
   NAST_REQUIRE(A && steps_out, "nast_lp_decode_f32: NULL args");
   // *steps_out < 0 on entry: never read the progress back -- all L steps are enqueued and the call returns without
   // synchronising (positions of finished sentences stay put, so the result's leading columns are the same)
@@ -109,9 +109,9 @@ extern "C" int nast_lp_decode_f32(const nast_lp_decode_args* A, int* steps_out, 
   const int B = A->B, S1 = A->S1, d = A->d, h = A->h, dff = A->dff, L = A->L, nl = A->nlayers;
   NAST_REQUIRE(B >= 1 && S1 >= 1 && d >= 1 && L >= 1 && nl >= 1 && nl <= 8 && h >= 1 && d % h == 0, "nast_lp_decode_f32: bad sizes");
   NAST_REQUIRE(h <= 64, "nast_lp_decode_f32: h > 64");
-  NAST_REQUIRE(A->layers && A->workspace && A->memory && A->origin_length && A->allpos, "nast_lp_decode_f32: NULL pointer");
-  NAST_REQUIRE((reinterpret_cast<uintptr_t>(A->workspace) & 255) == 0, "nast_lp_decode_f32: workspace must be 256-B aligned");
-  Ws w = carve(A->workspace, B, S1, d, dff, L, nl, h);
+  NAST_REQUIRE(A->layers && workspace && A->memory && A->origin_length && A->allpos, "nast_lp_decode_f32: NULL pointer");
+  NAST_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "nast_lp_decode_f32: workspace must be 256-B aligned");
+  Ws w = carve(workspace, B, S1, d, dff, L, nl, h);
   const int NC = S1 + 5;
   const float scale = 1.0f / sqrtf((float)(d / h));
   const bool fuse_ln = (B <= 1024 && d <= 256 && (d & 3) == 0);
@@ -121,18 +121,19 @@ extern "C" int nast_lp_decode_f32(const nast_lp_decode_args* A, int* steps_out, 
   hipLaunchKernelGGL(lp_init_kernel, dim3(B), dim3(256), 0, s, A->memory, A->pos_w, w.x, w.now_pos, A->allpos, B, S1, d, L + 1);
   NAST_CHECK_LAUNCH("nast_lp_decode_f32(init)");
   {   // wk(candidates), wk(unk), cross-attention K/V of every layer: grouped launches
-    std::vector<nast_gemm_desc> g;
-    g.push_back(lin(w.cand, B * NC, d, A->wk_w, A->wk_b, d, w.KC, d));
-    g.push_back(lin(A->unk, 1, d, A->wk_w, A->wk_b, d, w.kunk, d));
-    TRY(nast_gemm_f32(g.data(), (int)g.size(), s));
-    g.clear();
+    nast_gemm_desc g[NAST_GEMM_MAX_GROUP];     // (fixed array: the call makes no host or device allocation)
+    int ng = 0;
+    g[ng++] = lin(w.cand, B * NC, d, A->wk_w, A->wk_b, d, w.KC, d);
+    g[ng++] = lin(A->unk, 1, d, A->wk_w, A->wk_b, d, w.kunk, d);
+    TRY(nast_gemm_f32(g, ng, s));
+    ng = 0;
     for (int i = 0; i < nl; ++i) {
       const nast_declayer_weights& Wt = A->layers[i];
-      g.push_back(lin(A->memory, B * S1, d, Wt.ca_wk, Wt.ca_bk, d, w.mk + (size_t)i * B * S1 * d, d));
-      g.push_back(lin(A->memory, B * S1, d, Wt.ca_wv, Wt.ca_bv, d, w.mv + (size_t)i * B * S1 * d, d));
-      if (g.size() == NAST_GEMM_MAX_GROUP || i == nl - 1) {
-        TRY(nast_gemm_f32(g.data(), (int)g.size(), s));
-        g.clear();
+      g[ng++] = lin(A->memory, B * S1, d, Wt.ca_wk, Wt.ca_bk, d, w.mk + (size_t)i * B * S1 * d, d);
+      g[ng++] = lin(A->memory, B * S1, d, Wt.ca_wv, Wt.ca_bv, d, w.mv + (size_t)i * B * S1 * d, d);
+      if (ng == NAST_GEMM_MAX_GROUP || i == nl - 1) {
+        TRY(nast_gemm_f32(g, ng, s));
+        ng = 0;
       }
     }
   }
@@ -215,4 +216,44 @@ extern "C" int nast_lp_decode_f32(const nast_lp_decode_args* A, int* steps_out, 
   *steps_out = steps;
   NAST_CHECK_LAUNCH("nast_lp_decode_f32");
   return NAST_OK;
+}
+
+extern "C" int nast_lp_decode_f32(const nast_lp_decode_args* A, int* steps_out, void* stream_) {
+  NAST_REQUIRE(A, "nast_lp_decode_f32: NULL args");
+  return lp_decode_impl(A, A->workspace, steps_out, (hipStream_t)stream_);
+}
+
+// ---- allocation-free variant ------------------------------------------------------------------------------------------
+// For callers that cannot allocate (HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the decode's
+// workspace (candidate tables, cross-attention K/V of every layer, the self-attention K/V caches, per-step activations) lives
+// in a file-scope device array instead of caller memory.  Each GPU the library runs on holds its own copy of the array
+// at its own address until the process ends; the address is looked up once per device with hipGetSymbolAddress and kept.
+#define NAST_LP_DECODE_STATIC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[NAST_LP_DECODE_STATIC_BYTES];
+static void* g_scratch_ptr[NAST_LP_DECODE_STATIC_MAX_DEVICES];      // per device; nullptr = not looked up yet
+
+extern "C" int nast_lp_decode_static_f32(const nast_lp_decode_args* A, int* steps_out, void* stream_) {
+  NAST_REQUIRE(A && steps_out, "nast_lp_decode_static_f32: NULL args");
+  NAST_REQUIRE(A->B >= 1 && A->S1 >= 1 && A->d >= 1 && A->dff >= 1 && A->L >= 1 && A->nlayers >= 1 && A->nlayers <= 8,
+               "nast_lp_decode_static_f32: bad sizes");
+  const int64_t need = nast_lp_decode_workspace_bytes(A->B, A->S1, A->d, A->dff, A->L, A->nlayers);
+  NAST_REQUIRE(need <= (int64_t)NAST_LP_DECODE_STATIC_BYTES,
+               "nast_lp_decode_static_f32: this decode needs %lld bytes of workspace, the built-in buffer holds %lld "
+               "(B=%d S1=%d d=%d L=%d layers=%d): use nast_lp_decode_f32 with a caller workspace",
+               (long long)need, (long long)NAST_LP_DECODE_STATIC_BYTES, A->B, A->S1, A->d, A->L, A->nlayers);
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NAST_LP_DECODE_STATIC_MAX_DEVICES) {
+    nast_set_error("nast_lp_decode_static_f32: hipGetDevice failed or device index %d out of range", dev);
+    return NAST_ELAUNCH;
+  }
+  if (g_scratch_ptr[dev] == nullptr) {      // first call on this device (which is current): its copy of the array
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || ptr == nullptr) {
+      nast_set_error("nast_lp_decode_static_f32: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+      return NAST_ELAUNCH;
+    }
+    g_scratch_ptr[dev] = ptr;
+  }
+  return lp_decode_impl(A, reinterpret_cast<float*>(g_scratch_ptr[dev]), steps_out, (hipStream_t)stream_);
 }

@@ -541,7 +541,9 @@ class LengthPredictor(nn.Module):
                                               unk_id=unk_id)
             return ops.align_viterbi(cost0, cost, origin_length, target_length)
 
-    def _native_decode(self, memory, origin_length, eos, unk, allpos_buf):
+    static_decode_workspace = False     # True: nast_lp_decode_static_f32 (the library's built-in workspace, no allocation)
+
+    def _native_decode(self, memory, origin_length, eos, unk, allpos_buf, static=None):
         from ._lib import DecLayerWeights, LPDecodeArgs, load
         import ctypes as C
         lib = load()
@@ -561,8 +563,11 @@ class LengthPredictor(nn.Module):
                     sl[2].layer_norm.weight, sl[2].layer_norm.bias, f[0].weight, f[0].bias, f[3].weight, f[3].bias]
             for (name, _), v in zip(DecLayerWeights._fields_, vals):
                 setattr(arr[i], name, v.data_ptr())
-        nbytes = lib.nast_lp_decode_workspace_bytes(B, S1, d, dff, L, len(layers))
-        ws = torch.empty(nbytes // 4 + 64, device=memory.device, dtype=torch.float32)
+        static = self.static_decode_workspace if static is None else static
+        ws = None
+        if not static:
+            nbytes = lib.nast_lp_decode_workspace_bytes(B, S1, d, dff, L, len(layers))
+            ws = torch.empty(nbytes // 4 + 64, device=memory.device, dtype=torch.float32)
         memory, origin_length, eos, unk = memory.contiguous(), origin_length.contiguous(), eos.contiguous(), unk.contiguous()
         a = LPDecodeArgs()
         a.B, a.S1, a.d, a.h, a.dff, a.L, a.nlayers = B, S1, d, layers[0].self_attn.h, dff, L, len(layers)
@@ -573,10 +578,9 @@ class LengthPredictor(nn.Module):
         a.pos_w = self.pos_embed.weight.data_ptr()
         a.eos, a.unk = eos.data_ptr(), unk.data_ptr()
         a.memory, a.origin_length, a.allpos = memory.data_ptr(), origin_length.data_ptr(), allpos_buf.data_ptr()
-        off = (-ws.data_ptr()) % 256
-        a.workspace = ws.data_ptr() + off
+        a.workspace = None if static else ws.data_ptr() + (-ws.data_ptr()) % 256
         steps = C.c_int(-1 if ops.ASYNC_DECODE else 0)       # -1: no early-exit read-backs, the call does not synchronise
-        ops.call("nast_lp_decode_f32", C.byref(a), C.byref(steps), ops._stream())
+        ops.call("nast_lp_decode_static_f32" if static else "nast_lp_decode_f32", C.byref(a), C.byref(steps), ops._stream())
         self._decode_keepalive = (ws, memory, eos, unk)       # the enqueued kernels still read them
         return steps.value
 
