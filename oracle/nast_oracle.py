@@ -66,9 +66,32 @@ def attention(w, p, q_in, kv_in, mask, h):
     return _lin(w, p + "fc.", a)
 
 
+# Test hook (tests/test_model_gpu.py, gate replay): None, or a callable (parameter prefix, pre-activation [B,n,4d]) -> bool
+# mask [B,n,4d] or None.  With a mask, the ReLU's BACKWARD uses it as the gate instead of (pre-activation > 0); the forward
+# is the plain ReLU.  Two fp32 implementations round a pre-activation that is ~1e-8 from zero to different sides in about one
+# of 1e7 elements; such a flipped gate changes one row of one weight gradient by percents although both results are valid
+# roundings.  Replaying the other side's gates removes that one discrete effect from a gradient comparison.
+RELU_GATES = None
+
+
+class _GateReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gate):
+        ctx.save_for_backward(gate)
+        return torch.relu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (gate,) = ctx.saved_tensors
+        return g * gate.to(g.dtype), None
+
+
 def ffn(w, p, x):
     """PositionwiseFeedForward (transformer.py:305-316): Linear, ReLU, Dropout(0), Linear."""
-    return _lin(w, p + "mlp.3.", torch.relu(_lin(w, p + "mlp.0.", x)))
+    pre = _lin(w, p + "mlp.0.", x)
+    gate = RELU_GATES(p, pre) if (RELU_GATES is not None and torch.is_grad_enabled()) else None
+    act = torch.relu(pre) if gate is None else _GateReLU.apply(pre, gate)
+    return _lin(w, p + "mlp.3.", act)
 
 
 def encoder_layer(w, p, x, mask, h):

@@ -162,6 +162,20 @@ def test_noise_stages_match_reference_captures():
     assert n == 12
 
 
+def test_reference_import_names_resolve_through_compat():
+    """the modules `main.py:9` / `seq2seq.py:14,16` import, under the reference's own names (compat/)."""
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from seq2seq import Seq2seq\n"
+            "from transformer import Network, StyleTransformer, Discriminator, LengthPredictor, scaled_attention\n"
+            "from utils import Storage, cuda, BaseModel, LongTensor, gumbel_max, generateMask, cuda_init, debug, try_cache\n"
+            "from utils.gumbel import gumbel_softmax, gumbel_max_with_mask, straight_max, onehot\n"
+            "import nast_amd.seq2seq, nast_amd.transformer\n"
+            "assert issubclass(Seq2seq, nast_amd.seq2seq.Seq2seq) and Network is nast_amd.transformer.Network\n"
+            "print('ok')\n") % (os.path.join(ROOT, "compat"), ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def test_preprocess_batch_and_temperature():
     from nast_amd.seq2seq import Seq2seq
     s = Seq2seq.__new__(Seq2seq)
