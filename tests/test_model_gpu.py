@@ -24,7 +24,7 @@ def relclose(a, b, tol=1e-4, what=""):
     assert err <= tol * scale + 1e-7, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
 
 
-def check_grads(module, gold, tol=2e-4, gscale=None):
+def check_grads(module, gold, tol=1e-4, gscale=None):
     """Every golden gradient must match; tolerance relative to the largest gradient in the model
     (per-tensor where the tensor's own scale is meaningful)."""
     named = dict(module.named_parameters())
@@ -56,14 +56,14 @@ def test_layers_golden():
         y = mha(x, kv, kv, masks[tag])
         (y * T(g[f"in/mha/{tag}/R"])).sum().backward()
         relclose(y, g[f"out/mha/{tag}/y"], what=tag)
-        relclose(x.grad, g[f"g/mha/{tag}/x"], 2e-4, tag)
+        relclose(x.grad, g[f"g/mha/{tag}/x"], 1e-4, tag)
         check_grads(mha, sub(g, f"g/mha/{tag}/w/"))
     enc = tf.EncoderLayer(32, 4, 0).to(DEV)
     load_weights(enc, sub(g, "w/enc/"))
     x.grad = None
     y = enc(x, masks["self_pad"])
     (y * T(g["in/enc/R"])).sum().backward()
-    relclose(y, g["out/enc/y"]); relclose(x.grad, g["g/enc/x"], 2e-4)
+    relclose(y, g["out/enc/y"]); relclose(x.grad, g["g/enc/x"], 1e-4)
     check_grads(enc, sub(g, "g/enc/w/"))
     dec = tf.DecoderLayer(32, 4, 0).to(DEV)
     load_weights(dec, sub(g, "w/dec/"))
@@ -71,7 +71,7 @@ def test_layers_golden():
         dec.zero_grad(); x.grad = None; mem.grad = None
         y = dec(x, mem, masks["cross_pad"], tm)
         (y * T(g[f"in/dec/{tag}/R"])).sum().backward()
-        relclose(y, g[f"out/dec/{tag}/y"]); relclose(x.grad, g[f"g/dec/{tag}/x"], 2e-4); relclose(mem.grad, g[f"g/dec/{tag}/mem"], 2e-4)
+        relclose(y, g[f"out/dec/{tag}/y"]); relclose(x.grad, g[f"g/dec/{tag}/x"], 1e-4); relclose(mem.grad, g[f"g/dec/{tag}/mem"], 1e-4)
         check_grads(dec, sub(g, f"g/dec/{tag}/w/"))
     # the fine-grained public pieces compose to the same numbers as the fused sublayers
     y2 = enc.sublayer[0](x, lambda z: enc.self_attn(z, z, z, masks["self_pad"]))
@@ -121,7 +121,7 @@ def test_style_transformer_golden(tag):
         relclose(ll, g["out/teacher_soft/length_loss"])
         loss = loss + (ll * T(g["in/teacher_soft/W"])).sum()
     loss.backward()
-    relclose(soft.grad, g["gx/teacher_soft/soft"], 2e-4)
+    relclose(soft.grad, g["gx/teacher_soft/soft"], 1e-4)
     check_grads(F, sub(g, "g/teacher_soft/"))
 
     F.zero_grad()
@@ -199,11 +199,11 @@ def test_style_transformer_packed_rows_golden():
         (nll_p * live).sum().backward()
     relclose(nll_p * live, nll_r * live, what="packed nll (soft source)")
     src_live = (torch.arange(soft.shape[1], device=DEV)[None] < sl[:, None]).unsqueeze(-1)
-    relclose(ops.unpack_rows(rows.grad, ps), s_ref.grad * src_live, 2e-4, what="grad wrt soft tokens")
+    relclose(ops.unpack_rows(rows.grad, ps), s_ref.grad * src_live, 1e-4, what="grad wrt soft tokens")
     _same_grads(F, ref)
 
 
-def _same_grads(model, ref, tol=2e-4):
+def _same_grads(model, ref, tol=1e-4):
     """Gradients of two models agree, relative to the largest gradient of the model (key biases have analytically zero
     gradients -- softmax is shift invariant -- whose rounding noise has no scale of its own)."""
     pairs = [(n, p.grad, q.grad) for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters())]
@@ -232,7 +232,7 @@ def test_discriminator_golden(disc):
     lp = D(soft, tl, style)
     relclose(lp, g["out/soft/log_probs"])
     (lp * T(g["in/soft/R"])).sum().backward()
-    relclose(soft.grad, g["gx/soft/soft"], 2e-4)
+    relclose(soft.grad, g["gx/soft/soft"], 1e-4)
     check_grads(D, sub(g, "g/soft/"))
 
 
@@ -246,29 +246,29 @@ def test_gumbel_api_golden():
             ret, ys = U.gumbel_max(x, tau=float(g[f"in/{name}/tau"]))
         relclose(ys, g[f"out/{name}/y_soft"]); relclose(ret, g[f"out/{name}/ret"])
         (ret * T(g[f"in/{name}/R_ret"])).sum().backward(retain_graph=True)
-        relclose(x.grad, g[f"g/{name}/from_ret"], 2e-4)
+        relclose(x.grad, g[f"g/{name}/from_ret"], 1e-4)
         x.grad = None
         (ys * T(g[f"in/{name}/R_soft"])).sum().backward()
-        relclose(x.grad, g[f"g/{name}/from_soft"], 2e-4)
+        relclose(x.grad, g[f"g/{name}/from_soft"], 1e-4)
     x = logits.clone().requires_grad_(True)
     with U.inject_noise([T(g["in/gumbel_softmax/E"])]):
         y = U.gumbel_softmax(x, tau=0.8)
     relclose(y, g["out/gumbel_softmax/y"])
     (y * T(g["in/gumbel_softmax/R"])).sum().backward()
-    relclose(x.grad, g["g/gumbel_softmax/x"], 2e-4)
+    relclose(x.grad, g["g/gumbel_softmax/x"], 1e-4)
     x = logits.clone().requires_grad_(True)
     with U.inject_noise([T(g["in/gumbel_max_with_mask/E"])]):
         y = U.gumbel_max_with_mask(x, T(g["in/gumbel_max_with_mask/mask"]))
     relclose(y, g["out/gumbel_max_with_mask/y"])
     (y * T(g["in/gumbel_max_with_mask/R"])).sum().backward()
-    relclose(x.grad, g["g/gumbel_max_with_mask/x"], 2e-4)
+    relclose(x.grad, g["g/gumbel_max_with_mask/x"], 1e-4)
     for allow in (0, 1):
         x = logits.clone().requires_grad_(True)
         yh, ys = U.straight_max(x, allow_gradient=bool(allow))
         relclose(yh, g[f"out/straight_max_{allow}/y_hard"]); relclose(ys, g[f"out/straight_max_{allow}/y_soft"])
         if allow:
             (yh * T(g["in/straight_max_1/R"])).sum().backward()
-            relclose(x.grad, g["g/straight_max_grad/x"], 2e-4)
+            relclose(x.grad, g["g/straight_max_grad/x"], 1e-4)
 
 
 @pytest.mark.parametrize("tag", ["simple", "learnable"])
@@ -304,9 +304,9 @@ def test_training_steps_golden(tag, mode, two_streams):
                 ret = (model.d_step(inc, 1.0, use_inference_z=True),)
             else:
                 ret = model.f_step(inc, 1.0, cyc_rec_enable=(mode == "f_step"), use_inference_z=True)
-        np.testing.assert_allclose(np.asarray(ret, dtype=np.float64), g[s + "out/ret"], rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(np.asarray(ret, dtype=np.float64), g[s + "out/ret"], rtol=1e-4, atol=1e-6)
         if float(g[s + "out/grad_norm"]) >= 0:
-            np.testing.assert_allclose(float(model.last_grad_norm), float(g[s + "out/grad_norm"]), rtol=2e-4)
+            np.testing.assert_allclose(float(model.last_grad_norm), float(g[s + "out/grad_norm"]), rtol=1e-4)
         gold_g = sub(g, s + "g/")
         gscale = max(float(np.abs(v).max()) for v in gold_g.values())
         named = dict(model.net.named_parameters())
@@ -317,10 +317,13 @@ def test_training_steps_golden(tag, mode, two_streams):
             w = named[k].detach().cpu().numpy()
             if short in gold_g:
                 gg = gold_g[short]
-                np.testing.assert_allclose(named[k].grad.cpu().numpy(), gg, rtol=1e-3, atol=1e-5 * gscale, err_msg=k)
+                # north_star's 1e-4, relative to the tensor's largest gradient (floor: 1e-3 of the model's largest)
+                tscale = max(float(np.abs(gg).max()), 1e-3 * gscale)
+                err = float(np.abs(named[k].grad.cpu().numpy() - gg).max())
+                assert err <= 1e-4 * tscale, f"grad {k}: err {err:.3e} scale {tscale:.3e}"
                 solid = np.abs(gg) > 1e-3 * gscale     # Adam's first steps are ill-conditioned where |g| ~ rounding noise
-                np.testing.assert_allclose(w[solid], v[solid], rtol=1e-4, atol=1e-5, err_msg=k)
-                np.testing.assert_allclose(w, v, rtol=0, atol=2.5e-4, err_msg=k)
+                np.testing.assert_allclose(w[solid], v[solid], rtol=1e-4, atol=1e-6, err_msg=k)
+                np.testing.assert_allclose(w, v, rtol=0, atol=2.5e-4, err_msg=k)       # elsewhere: bounded by Adam's step
             else:
                 np.testing.assert_allclose(w, v, rtol=1e-6, atol=1e-7, err_msg=k)
 
