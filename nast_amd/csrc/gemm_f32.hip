@@ -31,6 +31,9 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float4& lo, const float4& hi) 
 #ifndef NAST_BK128
 #define NAST_BK128 32
 #endif
+#ifndef NAST_GEMM_LAB
+#define NAST_GEMM_LAB 0      // ablation builds only (tools/gemm_lab.sh): 1 = no global loads after the first K-tile, 2 = no LDS stores
+#endif                       // after the first, 4 = fragments read once per K-tile only; results are then wrong by construction
 
 struct GemmLaunch {
   nast_gemm_desc d[NAST_GEMM_MAX_GROUP];
@@ -212,7 +215,7 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
     const int cur = step & 1;
     const float* As = smem + cur * (GA::SZ + GB::SZ);
     const float* Bs = As + GA::SZ;
-    if (step + 1 < steps) issue(step + 1);
+    if (step + 1 < steps && !(NAST_GEMM_LAB & 1)) issue(step + 1);
 
     // fragments are double-buffered across the 8-wide k-groups: the LDS reads of group g+1 are in flight
     // while the 4 x MT x NT MFMAs of group g issue
@@ -266,12 +269,19 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
     for (int g = 0; g < NG; ++g) {
       const int c = g & 1, n = c ^ 1;
       if (g + 1 < NG) {
+        if (NAST_GEMM_LAB & 4) {
+#pragma unroll
+          for (int a = 0; a < MT; ++a) fa[n][a] = fa[c][a];
+#pragma unroll
+          for (int b = 0; b < NT; ++b) fb[n][b] = fb[c][b];
+        } else {
 #pragma unroll
         for (int a = 0; a < MT; ++a) fa[n][a] = frag_read<BM, BK, AKC>(As, wm * WTM + a * 32 + li, g + 1, lh);
 #pragma unroll
         for (int b = 0; b < NT; ++b) fb[n][b] = frag_read<BN, BK, BKC>(Bs, wn * WTN + b * 32 + li, g + 1, lh);
+        }
       }
-      if (g == NG / 2 && step + 1 < steps) {
+      if (g == NG / 2 && step + 1 < steps && !(NAST_GEMM_LAB & 2)) {
         // the next tile's LDS image is written in the middle of this tile's MFMA stream (its buffer was last
         // read before the previous barrier), so the stores issue in the shadow of the matrix pipe
         float* An = smem + (cur ^ 1) * (GA::SZ + GB::SZ);
@@ -395,7 +405,7 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
         if (flags & NAST_GEMM_RELU) v = fmaxf(v, 0.f);
         v = sv[r] > 0.f ? v : 0.f;
         if (col_ok && row < M) {
-          if (flags & NAST_GEMM_ATOMIC) atomicAdd(Cp + o, v);
+          if (flags & NAST_GEMM_ATOMIC) { if (!(NAST_GEMM_LAB & 8)) atomicAdd(Cp + o, v); }
           else if (flags & NAST_GEMM_ACCUM) Cp[o] += v;
           else Cp[o] = v;
         }
@@ -598,6 +608,9 @@ static void launch_skinny(const nast_gemm_desc* descs, int count, hipStream_t st
   hipLaunchKernelGGL(nast_gemm_f32_skinny_kernel, dim3(start), dim3(256), 0, stream, P);
 }
 
+bool nast_gemm_bstat_eligible(const nast_gemm_desc& D);                                   // gemm_bstat.hip
+int nast_gemm_bstat_launch(const nast_gemm_desc* descs, int count, hipStream_t stream);
+
 static bool xcd_split_too(int sk) {   // tuning aid: NAST_GEMM_XCD_SPLIT=0 keeps split-K problems out of the swizzle
   static const bool on = [] { const char* e = getenv("NAST_GEMM_XCD_SPLIT"); return e ? atoi(e) != 0 : true; }();
   return sk == 1 || on;
@@ -675,8 +688,8 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
     sk = (nkt + per - 1) / per;
     if (sk < 1) sk = 1;
     if (sk >= 2 && !(descs[i].flags & NAST_GEMM_ATOMIC)) {
-      if (descs[i].ldc == descs[i].N) hipMemsetAsync(descs[i].C, 0, (size_t)descs[i].M * descs[i].N * 4, stream);
-      else hipMemset2DAsync(descs[i].C, (size_t)descs[i].ldc * 4, 0, (size_t)descs[i].N * 4, descs[i].M, stream);
+      if (descs[i].ldc == descs[i].N) (void)hipMemsetAsync(descs[i].C, 0, (size_t)descs[i].M * descs[i].N * 4, stream);
+      else (void)hipMemset2DAsync(descs[i].C, (size_t)descs[i].ldc * 4, 0, (size_t)descs[i].N * 4, descs[i].M, stream);
       P.d[i].flags |= NAST_GEMM_ATOMIC;
     }
     per_of[i] = per; sk_of[i] = sk; order[i] = i;
@@ -775,33 +788,64 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
   const bool skinny = skinny_ok(descs, count);
   for (int i = 0; i < count; ++i)
     NAST_REQUIRE(descs[i].ln_gamma == nullptr || skinny, "nast_gemm_f32[%d]: fused LayerNorm needs the small-M path (M<=1024, K<=256, x W^T)", i);
-  int tilesL = 0;
-  plan_and_launch<128, 128, NAST_BK128>(descs, count, stream, true, &tilesL);
-  const int prof_kind = skinny ? 4 : 1;
-  nast_prof_before(prof_kind, stream);
-  if (skinny) launch_skinny(descs, count, stream);
-  else {
+  auto signature = [&](const char* head, const nast_gemm_desc* ds, int n) {
+    std::string sig = head;
+    for (int i = 0; i < n; ++i) {
+      const nast_gemm_desc& d = ds[i];
+      char b[160];
+      snprintf(b, sizeof(b), " [%dx%dx%d ta%d tb%d x%d f%d%s%s%s%s]", d.M, d.N, d.K, d.transA, d.transB, d.nsrc, d.flags,
+               d.bias ? " b" : "", d.residual ? " r" : "", d.colsum ? " cs" : "", d.ln_gamma ? " ln" : "");
+      sig += b;
+    }
+    return sig;
+  };
+  auto flops_of = [](const nast_gemm_desc* ds, int n) {
+    double f = 0;
+    for (int i = 0; i < n; ++i) f += 2.0 * ds[i].M * ds[i].N * (double)ds[i].K * ds[i].nsrc;
+    return f;
+  };
+  if (skinny) {
+    nast_prof_before(4, stream);
+    launch_skinny(descs, count, stream);
+    if (nast_prof_shapes(4)) nast_prof_after(4, stream, flops, signature("skinny", descs, count).c_str());
+    else nast_prof_after(4, stream, flops);
+    NAST_CHECK_LAUNCH("nast_gemm_f32");
+    return NAST_OK;
+  }
+  // Opt-in (NAST_GEMM_BSTAT=1): the d_model-deep projections (K = 256, plain row-major A) go to the weight-stationary kernel
+  // of gemm_bstat.hip, everything else of the group to the tiled kernel (two launches on the same stream).  Measured in
+  // round 2 (tools/gemm_bench, tools/bstat_lab.cpp): its marginal rate is higher (128 against 109 TFLOP/s per added row on
+  // x W1^T) but every launch first pays ~7 us for 512 workgroups pulling the same 128-KB weight panel through L2, so at the
+  // step's 9.7k rows it ties on QKV / FFN-1 (47.0 vs 46.6 us, 55.3 vs 57.7 us) and loses on the 256-column projection (23.4
+  // vs 20.9 us); it wins 10-15 % from ~19k rows.  Off by default for that reason.
+  const char* bstat_env = getenv("NAST_GEMM_BSTAT");
+  const bool bstat_on = bstat_env != nullptr && atoi(bstat_env) != 0;
+  nast_gemm_desc ws[NAST_GEMM_MAX_GROUP], rest[NAST_GEMM_MAX_GROUP];
+  int nws = 0, nrest = 0;
+  for (int i = 0; i < count; ++i) {
+    if (bstat_on && nast_gemm_bstat_eligible(descs[i])) ws[nws++] = descs[i];
+    else rest[nrest++] = descs[i];
+  }
+  if (nws > 0) {
+    nast_prof_before(1, stream);
+    nast_gemm_bstat_launch(ws, nws, stream);
+    if (nast_prof_shapes(1)) nast_prof_after(1, stream, flops_of(ws, nws), signature("ws", ws, nws).c_str());
+    else nast_prof_after(1, stream, flops_of(ws, nws));
+  }
+  if (nrest > 0) {
+    int tilesL = 0;
+    plan_and_launch<128, 128, NAST_BK128>(rest, nrest, stream, true, &tilesL);
+    nast_prof_before(1, stream);
     static const int force = [] { const char* e = getenv("NAST_GEMM_TILE"); return e ? atoi(e) : -1; }();   // tuning aid
     // measured (tools/gemm_bench, NAST_GEMM_TILE=0/2): the 64x64 tile at 4 workgroups per CU beats 128x128 at 2 on
     // every d_model-sized problem of the step (finer quantisation over 256 CUs, prologue/epilogue of one
     // workgroup hidden behind three others); 128x128 only wins (3-8 %) once there are thousands of tiles
     int cfg = tilesL >= 4096 ? 2 : 0;
     if (force >= 0) cfg = force;
-    if (cfg == 2) plan_and_launch<128, 128, NAST_BK128>(descs, count, stream, false, nullptr);
-    else plan_and_launch<64, 64, 32>(descs, count, stream, false, nullptr);
-  }
-  if (nast_prof_shapes(prof_kind)) {
-    std::string sig = skinny ? "skinny" : (tilesL >= 4096 ? "t128" : "t64");
-    for (int i = 0; i < count; ++i) {
-      const nast_gemm_desc& d = descs[i];
-      char b[160];
-      snprintf(b, sizeof(b), " [%dx%dx%d ta%d tb%d x%d f%d%s%s%s%s]", d.M, d.N, d.K, d.transA, d.transB, d.nsrc, d.flags,
-               d.bias ? " b" : "", d.residual ? " r" : "", d.colsum ? " cs" : "", d.ln_gamma ? " ln" : "");
-      sig += b;
-    }
-    nast_prof_after(prof_kind, stream, flops, sig.c_str());
-  } else {
-    nast_prof_after(prof_kind, stream, flops);
+    if (cfg == 2) plan_and_launch<128, 128, NAST_BK128>(rest, nrest, stream, false, nullptr);
+    else plan_and_launch<64, 64, 32>(rest, nrest, stream, false, nullptr);
+    if (nast_prof_shapes(1)) nast_prof_after(1, stream, flops_of(rest, nrest), signature(tilesL >= 4096 ? "t128" : "t64", rest, nrest).c_str());
+    else nast_prof_after(1, stream, flops_of(rest, nrest));
   }
   NAST_CHECK_LAUNCH("nast_gemm_f32");
   return NAST_OK;

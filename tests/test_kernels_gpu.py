@@ -52,6 +52,52 @@ def test_gemm_linear_fwd_bwd(ops, M, N, K):
     relclose(rg.grad, rr.grad)
 
 
+@pytest.mark.parametrize("M", [1040, 2049, 9733])
+@pytest.mark.parametrize("N,transB", [(128, 1), (256, 1), (1024, 1), (256, 0), (1024, 0)])
+def test_gemm_weight_stationary(ops, M, N, transB, monkeypatch):
+    """The (opt-in, NAST_GEMM_BSTAT=1) weight-stationary kernel (gemm_bstat.hip: K = 256, plain row-major A, N % 128 == 0, M > 1024) through the C-ABI:
+    every epilogue it fuses (bias, residual, ReLU, ReLU mask), both weight layouts, row counts that are not a multiple of the
+    16-row tile, a strided A, and a grouped launch of three problems -- against float64 on the CPU."""
+    from nast_amd._lib import GEMM_RELU
+    monkeypatch.setenv("NAST_GEMM_BSTAT", "1")
+    K = 256
+    g = torch.Generator().manual_seed(M + N + transB)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / 16                      # [N, K]
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    msk = torch.randn(M, N, generator=g)
+    xd, bd, rd, md = dev(x), dev(b), dev(res), dev(msk)
+    Bd = dev(W if transB else W.t().contiguous())                # transB=0: stored [K, N]
+    ldb = K if transB else N
+    ref = x.double() @ W.double().t()
+
+    def run(**kw):
+        y = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm([ops.desc(xd, Bd, y, M, N, K, K, ldb, N, 0, transB, **kw)])
+        return y
+
+    relclose(run(), ref)
+    relclose(run(bias=bd), ref + b.double())
+    relclose(run(bias=bd, residual=rd), ref + b.double() + res.double())
+    relclose(run(bias=bd, flags=GEMM_RELU), torch.relu(ref + b.double()))
+    relclose(run(relu_src=md), ref * (msk > 0))
+    relclose(run(bias=bd, residual=rd, relu_src=md, alpha=0.5), (0.5 * ref + b.double() + res.double()) * (msk > 0))
+    # A as a column block of a wider buffer (lda > K)
+    wide = torch.randn(M, K + 64, generator=g)
+    wd = dev(wide)
+    y = torch.empty(M, N, device="cuda")
+    ops.gemm([ops.desc(wd[:, 32:], Bd, y, M, N, K, K + 64, ldb, N, 0, transB)])
+    relclose(y, wide[:, 32:32 + K].double() @ W.double().t())
+    # three problems in one launch (QKV), different weights and outputs
+    Ws = [torch.randn(N, K, generator=g) / 16 for _ in range(3)]
+    ys = [torch.empty(M, N, device="cuda") for _ in range(3)]
+    Wd = [dev(w if transB else w.t().contiguous()) for w in Ws]            # (kept alive: a descriptor holds a bare pointer)
+    ops.gemm([ops.desc(xd, w, y_, M, N, K, K, ldb, N, 0, transB, bias=bd) for w, y_ in zip(Wd, ys)])
+    for w, y_ in zip(Ws, ys):
+        relclose(y_, x.double() @ w.double().t() + b.double())
+
+
 def test_gemm_relu_and_matmul_nn(ops):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(130, 48, generator=g)
