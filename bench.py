@@ -80,8 +80,19 @@ def build_model(cfg, device):
     return model
 
 
-def cpu_baseline(model, cfg, B, steps=2):
-    B = min(B, 128)      # bounded sample: CPU throughput of this path is flat in the batch size
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(model, cfg, B, steps=5, warm=2):
+    B = min(B, 64)       # bounded sample (the reference's own batch size): CPU throughput of this path is flat in the batch size
     """The CPU oracle (oracle/nast_oracle.py, pinned against the reference by the golden fixtures) timed on this
     box's host cores on a bounded sample of the same workload."""
     from oracle import nast_oracle as O
@@ -92,7 +103,7 @@ def cpu_baseline(model, cfg, B, steps=2):
     inc = synth_incoming(B, cfg["L"], cfg["V"], 1234, "cpu")
     sent, slen, dom = inc.data.sent, inc.data.sent_length, inc.data.domain
     times = []
-    for i in range(steps + 1):
+    for i in range(steps + warm):
         np.random.seed(i)
         ntok, nlen = model.net.noiseLayer(sent.t(), slen, 1 - dom)
         ntok = ntok.t().contiguous().cpu(); nlen = nlen.cpu()
@@ -106,11 +117,13 @@ def cpu_baseline(model, cfg, B, steps=2):
         t1 = time.perf_counter()
         tr.f_step(sent, slen, dom, ntok, nlen, [E])
         t2 = time.perf_counter()
-        if i > 0:
+        if i >= warm:
             times.append(t2 - t1)      # the shape probe (t1 - t0) is harness overhead, not part of the step
     sps = B / (sum(times) / len(times))
-    return {"value": round(sps, 2), "unit": "sentences/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} f_step of the same workload on a {B}-sentence sample after 1 warm-up, torch CPU fp32, {threads} threads"}
+    return {"value": round(sps, 2), "unit": "sentences/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
+            "host_cpus": os.cpu_count(),
+            "sample": f"{steps} f_step of the same workload on a {B}-sentence sample after {warm} warm-up steps, torch CPU fp32, "
+                      f"{threads} threads"}
 
 
 def main():
@@ -150,10 +163,13 @@ def main():
                 os.environ.setdefault(k, v)
             import nast_amd.ddp as _ddp
             _ddp.FORCE_SINGLE = True
+        # a collective that never completes ends the job with RCCL's watchdog message after this long, not at the job's limit
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("NAST_DDP_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     learnable = a.alignment == "learnable"
     L = a.max_length or (32 if learnable else 16)
     cfg = dict(V=9600, d=256, h=4, N=4, L=L, learnable=learnable)

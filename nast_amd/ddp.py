@@ -16,17 +16,30 @@ the parameter group being stepped:
     gather, the soft-token GEMM and the eos/unk rows), so the number per parameter is learnt on the first
     armed step of each step variant (`tag`) -- that step reduces after backward, un-overlapped;
   * if a later step produces a contribution after its bucket has left (the graph changed), the step falls
-    back to a full synchronous reduce and the plan is re-learnt: never a stale gradient;
+    back to a full synchronous reduce and the plan is re-learnt: never a stale gradient.  That decision (and the one to
+    learn a plan) is taken by ALL ranks together: `finish()` all-reduces a 2-word state (needs-redo flag, layout checksum)
+    after the buckets, so no rank can issue a different sequence of collectives than its peers; a checksum mismatch (ranks
+    whose backward graphs differ) raises instead of mixing gradients;
+  * the bucket LAYOUT is a function of the parameter list alone (reverse registration order, as torch DDP does), not of the
+    order in which a rank happened to see its gradients complete; the learnt contribution counts only decide when a bucket may
+    leave;
+  * every wait has a deadline (`NAST_DDP_TIMEOUT_S`, default 120 s): a stuck collective prints which rank waits for which
+    bucket of which step variant and raises, instead of hanging until the job's time limit;
   * parameters that never receive a gradient (sos_token, transformer.py:41; all of F during d_step) take no part.
 
 Local losses are divided by the LOCAL batch size (as the reference divides by its batch size); averaging
 the gradients over ranks therefore equals the single-GPU gradient on the concatenated batch when all ranks
 hold equally many sentences.
 """
+import datetime
 import os
+import sys
+import zlib
 
 import torch
 import torch.distributed as dist
+
+TIMEOUT_S = float(os.environ.get("NAST_DDP_TIMEOUT_S", "120"))
 
 _reducers = []
 FORCE_SINGLE = False   # rehearsal aid: reduce even in a process group of one rank (exercises the RCCL path on a one-GPU box)
@@ -97,8 +110,10 @@ class GradReducer:
             self._dirty = True                  # a contribution arrived after the bucket left
         elif self._seen[i] == plan.counts[i]:
             self._ready[b] += 1
-            if self._ready[b] == len(plan.buckets[b]):
-                self._launch(b)
+            # buckets leave strictly in layout order (collectives are matched across ranks by issue order)
+            while self._next < len(plan.buckets) and self._ready[self._next] == len(plan.buckets[self._next]):
+                self._launch(self._next)
+                self._next += 1
 
     def arm(self, tag="default", streams=()):
         """Call right before the backward pass whose gradients are final for this step.  `streams`: every HIP
@@ -117,13 +132,16 @@ class GradReducer:
             self._ready = [0] * n
             self._launched = [False] * n
             self._work = [None] * n
+            self._next = 0
 
     def _build_plan(self):
         counts, last = {}, {}
         for pos, i in enumerate(self._fired):
             counts[i] = counts.get(i, 0) + 1
             last[i] = pos
-        order = sorted(last, key=last.get)      # by the time the gradient became final
+        # layout: reverse registration order of the parameters that take part (a function of the model, identical on every
+        # rank); gradients become final roughly in that order, so the first bucket still leaves early in backward
+        order = sorted(last, reverse=True)
         buckets, cur, size = [], [], 0
         for i in order:
             n = self.params[i].numel() * self.params[i].element_size()
@@ -135,6 +153,7 @@ class GradReducer:
         if cur:
             buckets.append(cur)
         plan = _Plan(counts, buckets)
+        plan.checksum = zlib.crc32(repr((sorted(counts.items()), buckets)).encode()) & 0x7FFFFF      # exact in fp32
         plan.flat = [torch.empty(sum(self.params[i].numel() for i in idxs), dtype=self.params[idxs[0]].dtype,
                                  device=self.params[idxs[0]].device) for idxs in buckets]
         return plan
@@ -179,31 +198,71 @@ class GradReducer:
             torch._foreach_mul_([v for _, v in pairs], 1.0 / self.world)
             torch._foreach_copy_([g for g, _ in pairs], [v for _, v in pairs])
 
+    def _wait(self, work, what):
+        """work.wait() with a deadline and a message that names the rank, the step variant and the bucket."""
+        try:
+            ok = work.wait(datetime.timedelta(seconds=TIMEOUT_S))
+        except Exception as e:                       # gloo raises on timeout; RCCL's watchdog aborts with its own message
+            ok, err = False, e
+        else:
+            err = None
+        if ok is False or err is not None:
+            rank = dist.get_rank(self.group)
+            launched = getattr(self, "_launched", [])
+            msg = (f"[nast_amd.ddp] rank {rank}: {what} of step variant '{self.tag}' did not complete within {TIMEOUT_S:.0f} s "
+                   f"(buckets launched {sum(bool(x) for x in launched)}/{len(launched)}, stats {self.stats}, "
+                   f"bucket sizes {[len(b) for b in self.plan.buckets] if self.plan else None}): {err}")
+            print(msg, file=sys.stderr, flush=True)
+            raise RuntimeError(msg)
+
+    def _agree(self, need_sync, checksum):
+        """All ranks learn whether ANY rank has to (re)do the reduce synchronously, and check that their bucket layouts
+        are the same.  Two words, one all-reduce (MAX) + one (MIN); the result is read on the host, where the step reads
+        its losses a moment later anyway."""
+        t = torch.tensor([float(need_sync), float(checksum), -float(checksum)], device=self.params[0].device)
+        self._wait(dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group, async_op=True), "state exchange")
+        any_sync, cmax, ncmin = t.tolist()
+        if checksum >= 0 and not need_sync and not any_sync and (cmax != checksum or -ncmin != checksum):
+            raise RuntimeError(f"[nast_amd.ddp] rank {dist.get_rank(self.group)}: bucket layouts differ between ranks for step "
+                               f"variant '{self.tag}' ({checksum} vs {cmax}/{-ncmin}): the ranks' backward graphs are not the same")
+        return bool(any_sync)
+
     def finish(self):
         """Call after that backward: waits for the buckets, writes the averaged gradients back."""
         if not self.enabled:
             return
         self.armed = False
-        if self.plan is not None and self._dirty:
-            # the graph differs from the learnt one: drain what was sent, then redo everything synchronously
+        local_sync = self.plan is None or self._dirty
+        # A rank with a plan sends ALL its buckets, in layout order, even when it already knows that it will have to redo the
+        # step (its peers, which may be clean, send theirs: the sequences of collectives must be the same everywhere)
+        if self.plan is not None:
+            for b in range(len(self.plan.buckets)):
+                if not self._launched[b]:
+                    self._launch(b)                     # (buckets whose last gradient did not come during backward)
             for b, w in enumerate(self._work):
-                if w is not None:
-                    w.wait()
-            self.plan = None
-            self.stats["redone"] += 1
-        if self.plan is None:
-            if not self._fired:
-                return
-            self.stats["learnt"] += 1
-            self.plan = self.plans[self.tag] = self._build_plan()
-            n = len(self.plan.buckets)
-            self._launched = [False] * n
-            self._work = [None] * n
-        else:
+                self._wait(w, f"bucket {b}")
+        any_sync = self._agree(local_sync, -1 if self.plan is None else self.plan.checksum)
+        if not any_sync:
             self.stats["overlapped"] += 1
-        for b in range(len(self.plan.buckets)):
-            if not self._launched[b]:
-                self._launch(b)
-        for b in range(len(self.plan.buckets)):
-            self._work[b].wait()
+            for b in range(len(self.plan.buckets)):
+                self._write_back(b)
+            return
+        # some rank has no plan yet or saw a contribution after its bucket had left (the graph differs from the learnt one):
+        # EVERY rank re-learns from what it saw in this backward and reduces synchronously -- never a stale gradient
+        if self.plan is not None:
+            self.stats["redone"] += 1
+        self.stats["learnt"] += 1
+        if not self._fired:
+            # (a rank without any gradient in this step variant: it still has to match its peers' collectives)
+            raise RuntimeError("[nast_amd.ddp] a rank produced no gradient in a step variant its peers reduce")
+        self.plan = self.plans[self.tag] = self._build_plan()
+        n = len(self.plan.buckets)
+        self._launched = [False] * n
+        self._work = [None] * n
+        for b in range(n):
+            self._launch(b)
+        for b in range(n):
+            self._wait(self._work[b], f"bucket {b} (synchronous)")
             self._write_back(b)
+        if self._agree(False, self.plan.checksum):
+            raise RuntimeError("[nast_amd.ddp] inconsistent state exchange")

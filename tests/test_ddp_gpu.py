@@ -28,8 +28,11 @@ learnable = sys.argv[2].startswith("learnable")
 if sys.argv[2].endswith("2streams"):          # the second-stream overlap that production batches (>= 4096 tokens) use
     Seq2seq.overlap_min_tokens = 0
     Seq2seq.pack_min_tokens = 0
-    # (one bucket here: several outstanding gloo collectives on CUDA tensors stall inside ProcessGroupGloo on this image;
-    # many small buckets leaving while backward still runs are covered on CPU by tests/test_host_cpu.py)
+if "multibucket" in sys.argv[2]:             # several buckets in flight while backward still runs (64 KiB each: ~8 buckets for F)
+    Seq2seq.overlap_min_tokens = 0
+    Seq2seq.pack_min_tokens = 0
+    import nast_amd.ddp as _d
+    _d.GradReducer.BUCKET_BYTES = 64 << 10
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cfg = dict(V=48, d=32, h=4, N=2, L=8, learnable=learnable, gen_approx_mode="soft", dis_approx_mode="soft")
@@ -97,16 +100,19 @@ for step in range(3):
         print("step", step, "max grad diff / max grad", worst, flush=True)
     dist.barrier()
 dist.destroy_process_group()
+if "multibucket" in sys.argv[2]:
+    assert len(dp.reducer_F.plans["f_full"].buckets) >= 2, [len(b) for b in dp.reducer_F.plans["f_full"].buckets]
+    print("buckets", [len(b) for b in dp.reducer_F.plans["f_full"].buckets], dp.reducer_F.stats, flush=True)
 print("ok", rank)
 '''
 
 
-@pytest.mark.parametrize("mode", ["simple", "learnable", "learnable-2streams"])
+@pytest.mark.parametrize("mode", ["simple", "learnable", "learnable-2streams", "learnable-multibucket"])
 def test_two_rank_step_equals_single_process(tmp_path, mode):
     script = tmp_path / "w.py"
     script.write_text(WORKER)
-    port = {"simple": "29621", "learnable": "29622", "learnable-2streams": "29623"}[mode]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    port = {"simple": "29621", "learnable": "29622", "learnable-2streams": "29623", "learnable-multibucket": "29624"}[mode]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2", OMP_NUM_THREADS="2", NAST_DDP_TIMEOUT_S="40")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, mode], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=150)[0].decode() for p in procs]
