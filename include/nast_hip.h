@@ -259,11 +259,14 @@ int nast_lp_gather_bwd_f32(const float* dout, const int64_t* origin_length, cons
  * qh = wq(hidden), hid = hidden [B,d]; KC = wk(cand_in) [B,S1+5,d]; kunk = wk(unk) [d]; cand_in [B,S1+5,d];
  * lin_w [4,d], lin_b [4]; now_pos int64 [B] (in/out); allpos int64 [B, ldp].
  * norm_w/norm_b (may be NULL): when given, `hid` is the un-normalised decoder output and the final
- * LayerNorm of HiddenDecoder.incremental_forward (transformer.py:376) is applied inside the kernel.    */
+ * LayerNorm of HiddenDecoder.incremental_forward (transformer.py:376) is applied inside the kernel.
+ * sample_u (may be NULL): NULL = z_decode_mode "max" (first maximum, :559).  Otherwise [B] uniform numbers in [0,1) for
+ * this step and the skip is DRAWN from softmax(logits) (z_decode_mode "sample", :560-561) by inverse CDF:
+ * delta = the first j with p_0 + ... + p_j > u (the last j with p_j > 0 if rounding leaves none).            */
 int nast_lp_step_f32(const float* qh, const float* hid, const float* KC, const float* kunk,
                      const float* lin_w, const float* lin_b, const float* cand_in, const float* unk,
                      const float* pos_w, const int64_t* origin_length, int64_t* now_pos, int64_t* allpos,
-                     float* x_next, const float* norm_w, const float* norm_b,
+                     float* x_next, const float* norm_w, const float* norm_b, const float* sample_u,
                      int B, int S1, int d, int step, int ldp, int write_next, void* stream);
 
 /* Skip logits of the teacher-forced branch (transformer.py:504-507, the einsum "bld,bltd->blt" over
@@ -299,6 +302,8 @@ typedef struct nast_lp_decode_args {
   const int64_t* origin_length;          /* [B] */
   int64_t* allpos;                       /* [B, L+1] out; column 0 = 0 */
   float* workspace;                      /* nast_lp_decode_workspace_bytes() bytes, 256-B aligned */
+  const float* sample_u;                 /* NULL: z_decode_mode "max".  Else [L,B] uniforms in [0,1): step k draws its
+                                            skips from softmax(logits) with row k (z_decode_mode "sample", :560-561) */
 } nast_lp_decode_args;
 
 int64_t nast_lp_decode_workspace_bytes(int B, int S1, int d, int dff, int L, int nlayers);

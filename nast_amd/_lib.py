@@ -38,7 +38,7 @@ class LPDecodeArgs(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "S1", "d", "h", "dff", "L", "nlayers")] + \
                [("layers", C.POINTER(DecLayerWeights))] + \
                [(n, c_fp) for n in ("norm_w", "norm_b", "wq_w", "wq_b", "wk_w", "wk_b", "lin_w", "lin_b", "pos_w", "eos", "unk",
-                                    "memory", "origin_length", "allpos", "workspace")]
+                                    "memory", "origin_length", "allpos", "workspace", "sample_u")]
 
 
 class Rows(C.Structure):
@@ -73,7 +73,7 @@ SIGNATURES = {
     "nast_noise_i64": [c_fp, c_fp, _i, _i, _i, c_fp, _d, c_fp, c_fp, _d, c_fp, c_fp, c_fp, _d, _d, _i64, _i64, _i64, _i, _i, c_fp, c_fp, c_fp],
     "nast_lp_gather_fwd_f32": [c_fp] * 7 + [_i] * 6 + [c_fp],
     "nast_lp_gather_bwd_f32": [c_fp] * 7 + [_i] * 7 + [c_fp],
-    "nast_lp_step_f32": [c_fp] * 15 + [_i] * 6 + [c_fp],
+    "nast_lp_step_f32": [c_fp] * 16 + [_i] * 6 + [c_fp],
     "nast_nll_gather_f32": [c_fp, Rows, c_fp, c_fp, _i, _i, c_fp],
     "nast_nll_log_softmax_bwd_f32": [c_fp, c_fp, Rows, c_fp, c_fp, Rows, _i, _i, _f, c_fp],
     "nast_lp_logits_fwd_f32": [c_fp] * 5 + [_i] * 4 + [c_fp],

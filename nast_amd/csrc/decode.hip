@@ -200,7 +200,8 @@ static int lp_decode_impl(const nast_lp_decode_args* A, float* workspace, int* s
     }
     TRY(nast_gemm_f32(&gq, 1, s));
     TRY(nast_lp_step_f32(w.qh, x, w.KC, w.kunk, A->lin_w, A->lin_b, w.cand, A->unk, A->pos_w, A->origin_length, w.now_pos, A->allpos, xn,
-                         A->norm_w, A->norm_b, B, S1, d, k, L + 1, k + 1 < L ? 1 : 0, s));
+                         A->norm_w, A->norm_b, A->sample_u ? A->sample_u + (int64_t)k * B : nullptr, B, S1, d, k, L + 1,
+                         k + 1 < L ? 1 : 0, s));
     float* t = x; x = xn; xn = t;
     steps = k + 1;
     if (early_exit && k % 5 == 0) {   // transformer.py:569: stop once every sentence has consumed its source

@@ -12,8 +12,9 @@ __global__ __launch_bounds__(256) void nast_lp_step_kernel(const float* __restri
                                                            const float* __restrict__ pos_w, const int64_t* __restrict__ olen_,
                                                            int64_t* __restrict__ now_pos, int64_t* __restrict__ allpos,
                                                            float* __restrict__ x_next, const float* __restrict__ norm_w,
-                                                           const float* __restrict__ norm_b, int B, int S1, int d, int step,
-                                                           int ldp, float sqrt_d, int write_next) {
+                                                           const float* __restrict__ norm_b, const float* __restrict__ sample_u,
+                                                           int B, int S1, int d, int step, int ldp, float sqrt_d,
+                                                           int write_next) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -54,6 +55,21 @@ __global__ __launch_bounds__(256) void nast_lp_step_kernel(const float* __restri
 #pragma unroll
   for (int j = 1; j < 4; ++j)
     if (logit[j] > best) { best = logit[j]; delta = j; }   // first maximum wins (:559)
+  if (sample_u) {                              // :560-561  multinomial(softmax(logits)) by inverse CDF on this step's uniform
+    float p[4], tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p[j] = expf(logit[j] - best); tot += p[j]; }
+    const float u = sample_u[b] * tot;
+    float c = 0.f;
+    int pick = -1, last = delta;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      c += p[j];
+      if (p[j] > 0.f) last = j;
+      if (pick < 0 && p[j] > 0.f && c > u) pick = j;
+    }
+    delta = pick < 0 ? last : pick;
+  }
   int64_t nxt = now + delta;
   if (nxt > S1) nxt = S1;                      // :565  (origin_seqlen + 1)
   if (lane == 0) {
@@ -71,7 +87,7 @@ __global__ __launch_bounds__(256) void nast_lp_step_kernel(const float* __restri
 extern "C" int nast_lp_step_f32(const float* qh, const float* hid, const float* KC, const float* kunk, const float* lin_w,
                                 const float* lin_b, const float* cand_in, const float* unk, const float* pos_w,
                                 const int64_t* origin_length, int64_t* now_pos, int64_t* allpos, float* x_next,
-                                const float* norm_w, const float* norm_b, int B, int S1,
+                                const float* norm_w, const float* norm_b, const float* sample_u, int B, int S1,
                                 int d, int step, int ldp, int write_next, void* stream) {
   NAST_REQUIRE(B >= 0 && S1 >= 1 && d >= 1 && step >= 0 && ldp >= step + 2, "nast_lp_step_f32: bad sizes");
   if (B == 0) return NAST_OK;
@@ -79,7 +95,7 @@ extern "C" int nast_lp_step_f32(const float* qh, const float* hid, const float* 
                "nast_lp_step_f32: NULL pointer");
   NAST_REQUIRE(!write_next || x_next, "nast_lp_step_f32: x_next NULL");
   hipLaunchKernelGGL(nast_lp_step_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, qh, hid, KC, kunk, lin_w, lin_b,
-                     cand_in, unk, pos_w, origin_length, now_pos, allpos, x_next, norm_w, norm_b, B, S1, d, step, ldp, sqrtf((float)d),
+                     cand_in, unk, pos_w, origin_length, now_pos, allpos, x_next, norm_w, norm_b, sample_u, B, S1, d, step, ldp, sqrtf((float)d),
                      write_next);
   NAST_CHECK_LAUNCH("nast_lp_step_f32");
   return NAST_OK;

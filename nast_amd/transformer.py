@@ -542,8 +542,9 @@ class LengthPredictor(nn.Module):
             return ops.align_viterbi(cost0, cost, origin_length, target_length)
 
     static_decode_workspace = False     # True: nast_lp_decode_static_f32 (the library's built-in workspace, no allocation)
+    sample_u = None                     # test hook: [max_length, B] uniforms for z_decode_mode == "sample"
 
-    def _native_decode(self, memory, origin_length, eos, unk, allpos_buf, static=None):
+    def _native_decode(self, memory, origin_length, eos, unk, allpos_buf, static=None, sample_u=None):
         from ._lib import DecLayerWeights, LPDecodeArgs, load
         import ctypes as C
         lib = load()
@@ -579,9 +580,12 @@ class LengthPredictor(nn.Module):
         a.eos, a.unk = eos.data_ptr(), unk.data_ptr()
         a.memory, a.origin_length, a.allpos = memory.data_ptr(), origin_length.data_ptr(), allpos_buf.data_ptr()
         a.workspace = None if static else ws.data_ptr() + (-ws.data_ptr()) % 256
+        if sample_u is not None:
+            assert sample_u.shape == (L, B) and sample_u.dtype == torch.float32 and sample_u.is_contiguous()
+        a.sample_u = None if sample_u is None else sample_u.data_ptr()
         steps = C.c_int(-1 if ops.ASYNC_DECODE else 0)       # -1: no early-exit read-backs, the call does not synchronise
         ops.call("nast_lp_decode_static_f32" if static else "nast_lp_decode_f32", C.byref(a), C.byref(steps), ops._stream())
-        self._decode_keepalive = (ws, memory, eos, unk)       # the enqueued kernels still read them
+        self._decode_keepalive = (ws, memory, eos, unk, sample_u)       # the enqueued kernels still read them
         return steps.value
 
     # -- forward ------------------------------------------------------------------------------
@@ -633,13 +637,19 @@ class LengthPredictor(nn.Module):
         if not use_inference_z:
             return origin_input, origin_length                                # :521-522 (as the reference)
 
-        # ---- greedy skip decoding (:525-570): the whole loop runs in native code (nast_lp_decode_f32) ----
-        if self.args.z_decode_mode != "max":
-            raise NotImplementedError("z_decode_mode='sample' is not implemented on the HIP path (reference default: max)")
+        # ---- skip decoding (:525-570): the whole loop runs in native code (nast_lp_decode_f32) ----
+        if self.args.z_decode_mode not in ("max", "sample"):
+            raise NotImplementedError("no such z_decode_mode")                # :562-563
         L = self.args.max_length
         with torch.no_grad():
             allpos_buf = torch.empty(batch_size, L + 1, dtype=torch.long, device=dev)
-            steps = self._native_decode(origin_input.detach(), origin_length, eos_embed.detach(), unk_embed.detach(), allpos_buf)
+            # "sample" (:560-561): one uniform per sentence and step from torch's generator, drawn up front; the skip
+            # kernel turns it into a multinomial draw by inverse CDF.  `sample_u` (test hook) injects the uniforms.
+            u = None
+            if self.args.z_decode_mode == "sample":
+                u = self.sample_u if self.sample_u is not None else torch.rand(L, batch_size, device=dev)
+            steps = self._native_decode(origin_input.detach(), origin_length, eos_embed.detach(), unk_embed.detach(), allpos_buf,
+                                        sample_u=u)
             ops.run_deferred()       # host work that can proceed while the decode runs (ops.async_decode)
             allpos = allpos_buf[:, :steps + 1].contiguous()
         dec_input = ops.lp_gather(origin_input, origin_length, allpos, eos_embed, unk_embed, None, 0, True)   # :576-578

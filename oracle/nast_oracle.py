@@ -293,10 +293,22 @@ def _dec_layer_step(w, p, x_new, cache, li, mem, src_mask, h):
     return x + ffn(w, p + "pw_ffn.", _ln(w, p + "sublayer.2.layer_norm.", x))        # :271
 
 
+def sample_skip(logits, u):
+    """z_decode_mode == "sample" (transformer.py:560-561: torch.multinomial(logits.softmax(-1), 1)) with the randomness
+    made an input: u [B] uniform in [0,1); the draw is the inverse CDF, delta = first j with p_0+..+p_j > u (a j with
+    p_j == 0 is never drawn; the last positive j if rounding leaves none)."""
+    p = torch.softmax(logits.double(), -1)
+    c = torch.cumsum(p, -1)
+    ok = (c > u.double().unsqueeze(-1)) & (p > 0)
+    first = torch.where(ok.any(-1), ok.float().argmax(-1), torch.full_like(u, -1, dtype=torch.long))
+    last = (p > 0).float().cumsum(-1).argmax(-1)
+    return torch.where(first >= 0, first, last)
+
+
 def length_predictor_generate(w, cfg, origin_input, origin_length, use_inference_z=True,
-                              lp="length_predictor.", ep="embed."):
-    """Greedy skip decoding (transformer.py:520-582, z_decode_mode == "max").
-    Returns dec_input[:, :maxT+1], target_length, allpos."""
+                              lp="length_predictor.", ep="embed.", sample_u=None):
+    """Skip decoding (transformer.py:520-582): z_decode_mode == "max" (sample_u None), or "sample" with the uniforms
+    sample_u [L,B] that `sample_skip` turns into draws.  Returns dec_input[:, :maxT+1], target_length, allpos."""
     if not use_inference_z:
         raise ValueError("reference raises here as well (transformer.py:78 vs :522)")
     B, n, d = origin_input.shape
@@ -322,7 +334,7 @@ def length_predictor_generate(w, cfg, origin_input, origin_length, use_inference
             if k == 0:
                 logits[:, 0] = -1e9
                 logits = logits - padded[:, :4] * 1e9                                  # :553-555
-            delta = logits.max(-1)[1]                                                  # :559 first max
+            delta = logits.max(-1)[1] if sample_u is None else sample_skip(logits, sample_u[k])   # :559 first max / :561
             now = torch.clamp(now + delta, max=S + 1)                                  # :565
             stay = (delta == 0).view(B, 1, 1).float()
             cols.append(now)
@@ -338,7 +350,7 @@ def length_predictor_generate(w, cfg, origin_input, origin_length, use_inference
 # StyleTransformer / Discriminator  (transformer.py:48-153)
 # ----------------------------------------------------------------------------------------------
 def style_transformer(w, cfg, inp_tokens, inp_lengths, gold_tokens, gold_lengths, style,
-                      generate=False, temperature=1.0, use_inference_z=True, p="model_F."):
+                      generate=False, temperature=1.0, use_inference_z=True, p="model_F.", sample_u=None):
     """Returns (log_probs[:,1:], tgt_lengths, length_loss, gen_error, allpos) like transformer.py:103."""
     w = _sub(w, p)
     B, S = inp_tokens.shape[0], inp_tokens.shape[1]
@@ -351,7 +363,8 @@ def style_transformer(w, cfg, inp_tokens, inp_lengths, gold_tokens, gold_lengths
     tgt_lengths = length_loss = gen_err = allpos = None
     if cfg.learnable:
         if generate:
-            dec_in, tgt_lengths, allpos = length_predictor_generate(w, cfg, dec_in, inp_lengths, use_inference_z)
+            dec_in, tgt_lengths, allpos = length_predictor_generate(w, cfg, dec_in, inp_lengths, use_inference_z,
+                                                                    sample_u=sample_u)
         else:
             dec_in, tgt_lengths, length_loss, gen_err, _ = length_predictor_teacher(
                 w, cfg, dec_in, inp_lengths, inp_tokens, gold_tokens, gold_lengths, use_inference_z)

@@ -321,3 +321,19 @@ def test_packed_seq_index_maps():
     soft = ops.PackedSoft(torch.zeros(ps.rows, 7), ps)
     assert soft.dim() == 3 and soft.size(0) == 4 and soft.size(1) == n and soft.shape == (4, n, 7)
     assert soft.column(3).shape == (4, n)
+
+
+def test_oracle_sample_skip_follows_softmax():
+    """oracle.sample_skip (the restatement of torch.multinomial(logits.softmax(-1), 1), transformer.py:560-561, with the
+    uniforms as an input): frequencies over many uniforms match softmax(logits); masked entries (-1e9) are never drawn."""
+    from oracle import nast_oracle as O
+    logits = torch.tensor([[-1e9, 0.3, -0.7, 1.1], [0.0, 0.0, 0.0, 0.0], [2.0, -1e9, -1e9, -1e9]])
+    n = 200000
+    u = torch.rand(n, generator=torch.Generator().manual_seed(0))
+    for row in logits:
+        d = O.sample_skip(row.expand(n, 4), u)
+        freq = torch.bincount(d, minlength=4).double() / n
+        p = torch.softmax(row.double(), -1)
+        assert (freq - p).abs().max() < 5e-3, (freq, p)
+        assert freq[p == 0].sum() == 0
+    assert O.sample_skip(logits[:1], torch.tensor([0.999999999])).item() == 3

@@ -639,6 +639,48 @@ def test_stress_shape_full_depth_bf16_vs_oracle():
     assert max(c["grad_err_vs_model_max"] for c in rep["classes"].values()) <= 2e-2, rep["classes"]
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_sample_decode_vs_oracle(seed):
+    """z_decode_mode == "sample" (transformer.py:560-561): with the same uniform numbers the HIP decode loop and the oracle's
+    inverse-CDF restatement draw the same skips, step after step (a draw feeds the next step's input), and the decoder run
+    on the drawn alignment matches.  The reference draws with torch.multinomial on its own generator, which no other
+    implementation can replay: what is pinned here is the distribution (softmax of the reference's logits) and the use of
+    the draw (:565-567), not the reference's random stream -- "parity unpinned" for the stream itself."""
+    from nast_amd import transformer as tf
+    from oracle import nast_oracle as O
+    g = load_golden("g2_style_transformer_learnable")
+    cfg = cfg_of(g)
+    param = make_param(**cfg)
+    param.args.z_decode_mode = "sample"
+    F = tf.StyleTransformer(param).to(DEV)
+    assert not load_weights(F, sub(g, "w/"))
+    gold, gl, style = T(g["in/gold"]), T(g["in/gold_len"]), T(g["in/style"])
+    B, L = gold.shape[0], cfg["L"]
+    u = torch.rand(L, B, generator=torch.Generator().manual_seed(seed))
+    w = {"model_F." + k: torch.from_numpy(np.asarray(v)) for k, v in sub(g, "w/").items()}
+    ocfg = O.Cfg(**{k: cfg[k] for k in ("V", "d", "h", "N", "L", "learnable")})
+    with torch.no_grad():
+        ref = O.style_transformer(w, ocfg, gold.cpu(), gl.cpu(), None, None, (1 - style).cpu(), True, 1.0, True, sample_u=u)
+        F.length_predictor.sample_u = u.to(DEV)
+        lp, tl, _, _, ap = F(gold, gl, None, None, 1 - style, generate=True, temperature=1.0, use_inference_z=True)
+    assert np.array_equal(ap.cpu().numpy(), ref[4].numpy())
+    assert np.array_equal(tl.cpu().numpy(), ref[1].numpy())
+    greedy = g["out/generate/allpos"]
+    assert not np.array_equal(ap.cpu().numpy()[:, :greedy.shape[1]], greedy[:, :ap.shape[1]]), "sampling must not reduce to the argmax path"
+    relclose(lp, ref[0], what="sampled generate")
+    # without injected uniforms the draws come from torch's generator: reproducible under a seed, different across seeds
+    F.length_predictor.sample_u = None
+    outs = []
+    for s in (7, 7, 8):
+        torch.manual_seed(s)
+        with torch.no_grad():
+            outs.append(F(gold, gl, None, None, 1 - style, generate=True, temperature=1.0, use_inference_z=True)[4].cpu())
+    assert torch.equal(outs[0], outs[1]) and not (outs[0].shape == outs[2].shape and torch.equal(outs[0], outs[2]))
+    param.args.z_decode_mode = "nope"
+    with pytest.raises(NotImplementedError):
+        F(gold, gl, None, None, 1 - style, generate=True, temperature=1.0, use_inference_z=True)
+
+
 def test_transfer_matches_golden_generate():
     """Seq2seq.transfer (the generator's share of evaluate, seq2seq.py:303-339) on the captured generate case: argmax
     tokens, generated lengths and alignment positions of the reference."""
