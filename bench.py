@@ -230,6 +230,25 @@ def main():
         dt = (time.perf_counter() - t1) / n_small
         also = {"bs64": {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_small}}
 
+        def graphed(m, data, n):
+            """the same step replayed from one HIP graph (nast_amd/graph.py): 2 eager fixed-width steps, capture, then timing"""
+            m.graph_steps = True
+            try:
+                for i in range(4):
+                    m.f_step(data[i % 4], 1.0, use_inference_z=True)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for i in range(n):
+                    m.f_step(data[i % 4], 1.0, use_inference_z=True)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / n
+            finally:
+                m.graph_steps = False
+
+        dtg = graphed(model, small, max(n_small, 10))
+        also["bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3),
+                              "note": "whole f_step replayed from one HIP graph (Seq2seq.graph_steps = True)"}
+
         def timed(fn, n):
             for _ in range(2):
                 fn(0)
@@ -242,7 +261,7 @@ def main():
 
         # the step without its optimizer, measured right behind the headline pass (clip + Adam skipped; forward + both backwards only)
         step_fn = model.optimizer_F.clip_and_step
-        model.optimizer_F.clip_and_step = lambda max_norm=None: None
+        model.optimizer_F.clip_and_step = lambda max_norm=None, capturing=False: None
         try:
             dt_fb = timed(lambda i: model.f_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
         finally:
@@ -260,6 +279,8 @@ def main():
         b1 = [synth_incoming(64, 16, 9600, 7000 + i, "cuda") for i in range(4)]
         dt = timed(lambda i: m1.f_step(b1[i % 4], 1.0, use_inference_z=True), min(a.steps, 10))
         also["configs1_simple_L16_bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3)}
+        dtg = graphed(m1, b1, 10)
+        also["configs1_simple_L16_bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3)}
         del m1
         if a.precision == "fp32":
             # north_star's bf16 variant: GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 storage + accumulate), same step

@@ -336,6 +336,8 @@ int nast_multi_adam_f32(float* const* params, float* const* grads /* scaled in p
                         const float* total_sqnorm /*device [1] or NULL*/, float max_norm,
                         float lr, float beta1, float beta2, float eps, float weight_decay,
                         float bias_c1, float bias_c2,
+                        const float* bias_dev /* device [2] = {bias_c1, bias_c2} read by the kernel instead of the two
+                                                 scalars, or NULL: for a replayed HIP graph, whose step count is on the device */,
                         const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_elems,
                         void* stream);
 /* chunk table (device arrays, or NULL for a (32, n) grid): chunk c covers elements chunk_off[c] .. +chunk_elems of tensor

@@ -82,7 +82,7 @@ SIGNATURES = {
     "nast_lp_decode_f32": [C.POINTER(LPDecodeArgs), C.POINTER(C.c_int), c_fp],
     "nast_lp_decode_static_f32": [C.POINTER(LPDecodeArgs), C.POINTER(C.c_int), c_fp],
     "nast_multi_sqnorm_f32": [c_fp, c_fp, _i, c_fp, c_fp, c_fp, _i, _i, c_fp],
-    "nast_multi_adam_f32": [c_fp] * 5 + [_i, c_fp] + [_f] * 8 + [c_fp, c_fp, _i, _i, c_fp],
+    "nast_multi_adam_f32": [c_fp] * 5 + [_i, c_fp] + [_f] * 8 + [c_fp, c_fp, c_fp, _i, _i, c_fp],
     "nast_prof_begin": [_i],
     "nast_prof_end": [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "nast_prof_get": [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)],

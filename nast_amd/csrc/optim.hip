@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void nast_multi_adam_kernel(float* const* __re
                                                               const int64_t* __restrict__ sizes, const float* __restrict__ total_sq,
                                                               float max_norm, float lr, float beta1, float beta2, float eps,
                                                               float weight_decay, float bias_c1, float bias_c2,
+                                                              const float* __restrict__ bias_dev,
                                                               const int32_t* __restrict__ chunk_tensor,
                                                               const int64_t* __restrict__ chunk_off, int chunk_elems) {
   const ChunkRange R = chunk_range(chunk_tensor, chunk_off, chunk_elems, sizes);
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256) void nast_multi_adam_kernel(float* const* __re
   }
   // operation order of torch.optim.Adam (_single_tensor_adam): exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g,
   // value=1-b2); denom = exp_avg_sq.sqrt() / sqrt(bias_c2) + eps; p.addcdiv_(exp_avg, denom, value=-lr/bias_c1)
+  if (bias_dev) { bias_c1 = bias_dev[0]; bias_c2 = bias_dev[1]; }   // a replayed HIP graph: the step count lives on the device
   const float step = lr / bias_c1;
   const float bc2_sqrt = sqrtf(bias_c2);
   const float w1 = 1.f - beta1, w2 = 1.f - beta2;
@@ -101,15 +103,16 @@ extern "C" int nast_multi_sqnorm_f32(const float* const* grads, const int64_t* s
 
 extern "C" int nast_multi_adam_f32(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                                    const int64_t* sizes, int n, const float* total_sqnorm, float max_norm, float lr, float beta1,
-                                   float beta2, float eps, float weight_decay, float bias_c1, float bias_c2, const int32_t* chunk_tensor,
-                                   const int64_t* chunk_off, int n_chunks, int chunk_elems, void* stream) {
+                                   float beta2, float eps, float weight_decay, float bias_c1, float bias_c2, const float* bias_dev,
+                                   const int32_t* chunk_tensor, const int64_t* chunk_off, int n_chunks, int chunk_elems,
+                                   void* stream) {
   NAST_REQUIRE(n >= 0 && n <= 65535, "nast_multi_adam_f32: n=%d out of range", n);
   if (n == 0) return NAST_OK;
   NAST_REQUIRE(params && grads && exp_avg && exp_avg_sq && sizes, "nast_multi_adam_f32: NULL pointer");
   NAST_REQUIRE(chunk_tensor == nullptr || (chunk_off != nullptr && n_chunks > 0 && chunk_elems > 0), "nast_multi_adam_f32: chunk table");
   const dim3 grid = chunk_tensor ? dim3(n_chunks) : dim3(32, n);
   hipLaunchKernelGGL(nast_multi_adam_kernel, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                     sizes, total_sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, chunk_tensor, chunk_off,
+                     sizes, total_sqnorm, max_norm, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, bias_dev, chunk_tensor, chunk_off,
                      chunk_elems);
   NAST_CHECK_LAUNCH("nast_multi_adam_f32");
   return NAST_OK;

@@ -1,0 +1,107 @@
+"""HIP-graph replay of the generator training step for small batches.
+
+At the reference's own batch size (64 sentences, run.py:70) one f_step is ~2000 kernel launches of a few microseconds each:
+the GPU finishes them faster than Python can issue them, and the step time is the host's.  `StepGraphs` captures the whole
+step -- NoiseLayer, the three generator passes with the greedy decode, the discriminator, both backward passes, the
+gradient clip and Adam -- into one HIP graph per (batch size, temperature, cyc_rec_enable, use_inference_z) and replays
+it: one launch per step.
+
+What makes the step capturable (all of it switched by ops.fixed_width, nothing else changes):
+  * shapes: every tensor keeps its maximum width (ops.FIXED_WIDTH); the batch is copied into static buffers of width
+    max_length, padded with <pad>; lengths mask the padding exactly as they do in the eager step;
+  * no read-backs: the decode runs without its early exit, widths are not trimmed, losses are read after the replay;
+  * randomness: NoiseLayer and the Gumbel noise draw through torch's generator, whose state a captured graph advances on
+    every replay (ops.GRAPH_NOISE);
+  * Adam: the step count lives on the device (FusedAdam.device_step_counter), the kernel reads its bias corrections there.
+The first `WARM` steps of a key run eagerly in the same fixed-width mode (they are real training steps; they also create
+the gradient buffers, optimizer state and pointer tables the capture relies on), the next call captures and replays.
+
+Single process only (a captured collective would need RCCL's own capture support); the packed large-batch step is not
+captured: there the GPU is the bound, and the packed layout needs the row totals on the host.
+"""
+import torch
+
+from . import ops
+from .utils import Storage
+
+
+class _Entry:
+    __slots__ = ("seen", "graph", "out", "sent", "length", "domain", "incoming")
+
+
+class StepGraphs:
+    WARM = 2
+
+    def __init__(self, trainer):
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise NotImplementedError("graph_steps: single process only")
+        self.tr = trainer
+        self.entries = {}
+        self.stats = {"eager": 0, "captured": 0, "replayed": 0}
+
+    def _entry(self, key, B, dev):
+        e = self.entries.get(key)
+        if e is None:
+            L = self.tr.args.max_length
+            e = _Entry()
+            e.seen, e.graph, e.out = 0, None, None
+            e.sent = torch.zeros(B, L, dtype=torch.int64, device=dev)
+            e.length = torch.zeros(B, dtype=torch.int64, device=dev)
+            e.domain = torch.zeros(B, dtype=torch.int64, device=dev)
+            e.incoming = Storage()
+            e.incoming.data = Storage()
+            e.incoming.data.sent, e.incoming.data.sent_length, e.incoming.data.domain = e.sent, e.length, e.domain
+            e.incoming.data.batch_size, e.incoming.data.seqlen = B, L
+            self.entries[key] = e
+        return e
+
+    def _load(self, e, incoming):
+        d = incoming.data
+        w = d.sent.shape[1]
+        pad = self.tr.param.volatile.dm.pad_id
+        if w > e.sent.shape[1]:
+            raise ValueError(f"graph_steps: batch width {w} exceeds max_length {e.sent.shape[1]}")
+        e.sent.fill_(pad)
+        e.sent[:, :w].copy_(d.sent, non_blocking=True)
+        e.length.copy_(d.sent_length, non_blocking=True)
+        e.domain.copy_(d.domain, non_blocking=True)
+
+    @staticmethod
+    def _pack(out):
+        z = None
+        vals = []
+        for x in out:
+            if x is None:
+                if z is None:
+                    z = next(v for v in out if v is not None).new_zeros(())
+                x = z
+            vals.append(x.detach().reshape(()).float())
+        return torch.stack(vals)
+
+    def f_step(self, incoming, temperature, cyc_rec_enable, use_inference_z):
+        tr = self.tr
+        sent = incoming.data.sent
+        B = sent.shape[0]
+        key = ("f", B, float(temperature), bool(cyc_rec_enable), bool(use_inference_z))
+        e = self._entry(key, B, sent.device)
+        self._load(e, incoming)
+        kw = dict(use_inference_z=use_inference_z)
+        if e.seen < self.WARM:
+            e.seen += 1
+            self.stats["eager"] += 1
+            with ops.packed_rows(False), ops.fixed_width():
+                out = self._pack(tr._f_step(e.incoming, temperature, cyc_rec_enable, **kw))
+            return tuple(out.tolist())
+        if e.graph is None:
+            tr.optimizer_F.device_step_counter()          # created (and validated) outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                with ops.packed_rows(False), ops.fixed_width():
+                    e.out = self._pack(tr._f_step(e.incoming, temperature, cyc_rec_enable, capturing=True, **kw))
+            e.graph = g
+            self.stats["captured"] += 1
+        e.graph.replay()
+        tr.optimizer_F.note_replayed_step()
+        self.stats["replayed"] += 1
+        return tuple(e.out.tolist())

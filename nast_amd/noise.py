@@ -119,7 +119,10 @@ class NoiseLayer(nn.Module):
         return out, l
 
     # ---- device path ---------------------------------------------------
-    device_side = True      # False: always the host (numpy) path, whose draws follow the reference's numpy stream
+    # True: the device path whenever the drop/repeat stage is on (the configurations of the learnable model); "always": also
+    # without it (blank / add only); False: always the host (numpy) path, whose draws follow the reference's numpy stream.
+    # The fixed-width execution (ops.FIXED_WIDTH, graph replay) implies "always": it cannot leave the device.
+    device_side = True
 
     def _forward_device(self, words, lengths, rev_domain):
         """Same stages, same functions of the draws (`ops.noise_tokens` == `*_apply`, bit-exact given the draws), but the
@@ -138,12 +141,15 @@ class NoiseLayer(nn.Module):
             dist = self.cnt[rev_domain.to(self.cnt.device)].to(dev)
             kw.update(u_add=torch.rand(M - 1, B, dtype=torch.float64, device=dev), add_prob=self.add_prob,
                       new_words=torch.multinomial(dist, M, True).transpose(0, 1).contiguous())
-        assert self.dropout_prob < 1 and self.repeat_prob < 1
-        assert not self.keep_go and self.keep_eos
-        kw.update(u_keep=torch.rand(M, B, dtype=torch.float64, device=dev), u_rep=torch.rand(M - 1, B, dtype=torch.float64, device=dev),
-                  u_pick=torch.rand(B, dtype=torch.float64, device=dev), dropout_prob=self.dropout_prob, repeat_prob=self.repeat_prob)
+        if self.dropout_prob != 0 or self.repeat_prob != 0:
+            assert self.dropout_prob < 1 and self.repeat_prob < 1
+            assert not self.keep_go and self.keep_eos
+            kw.update(u_keep=torch.rand(M, B, dtype=torch.float64, device=dev), u_rep=torch.rand(M - 1, B, dtype=torch.float64, device=dev),
+                      u_pick=torch.rand(B, dtype=torch.float64, device=dev), dropout_prob=self.dropout_prob, repeat_prob=self.repeat_prob)
         out, new_len = ops.noise_tokens(words, lengths, M, pad=self.pad_index, unk=self.blank_index, eos=self.eos_index,
                                         keep_go=self.keep_go, keep_eos=self.keep_eos, **kw)
+        if ops.FIXED_WIDTH:                     # graph replay: keep the full width (new_len <= M), read nothing back
+            return out[:M], new_len
         width, total = torch.stack((new_len.max(), new_len.sum())).tolist()
         new_len.nast_total = int(total)
         return out[:width], new_len
@@ -152,9 +158,14 @@ class NoiseLayer(nn.Module):
     def forward(self, words, lengths, rev_domain):
         """words [seq,B] int64, lengths [B], rev_domain [B] -> (noisy words [seq',B], lengths [B]) on words.device.
         Stage order and draw order follow noise.py:60-74 (shuffle, blank, add, dropout)."""
+        from . import ops
         dev = words.device
-        if self.device_side and words.is_cuda and self.shuffle_weight == 0 and (self.dropout_prob != 0 or self.repeat_prob != 0):
+        if self.device_side and words.is_cuda and self.shuffle_weight == 0 and (
+                self.dropout_prob != 0 or self.repeat_prob != 0 or self.device_side == "always" or ops.FIXED_WIDTH):
             return self._forward_device(words, lengths, rev_domain)
+        if ops.FIXED_WIDTH:
+            raise NotImplementedError("NoiseLayer: the fixed-width (graph) execution needs the device path "
+                                      "(CUDA input, word_shuffle == 0)")
         x = words.detach().cpu().numpy()
         l = lengths.detach().cpu().numpy().astype(np.int64)
         M = self.max_length

@@ -468,6 +468,32 @@ def run_deferred():
 PACK_ROWS = False
 PACK_MAX_LEN = 64            # limit of the packed attention kernels
 
+# Fixed-shape execution (nast_amd/graph.py: HIP-graph replay of a training step).  The step normally trims tensors to the
+# longest sentence of the batch -- NoiseLayer's output, the generated sentences -- which costs a device-to-host read each and
+# makes every step a different sequence of launches.  With FIXED_WIDTH those tensors keep their maximum width (max_length;
+# max_length + 1 decoder positions), nothing is read back, and the padding is masked by the lengths as it always is.
+# GRAPH_NOISE: the Gumbel noise is drawn by torch (exponential_, whose generator state a captured graph advances on every
+# replay) instead of the row kernel's own Philox stream, whose seed and offset are kernel arguments fixed at capture.
+FIXED_WIDTH = False
+GRAPH_NOISE = False
+
+
+class fixed_width:
+    """with ops.fixed_width(): ...   maximum-width tensors, no read-backs (see FIXED_WIDTH)."""
+
+    def __init__(self, on=True, graph_noise=None):
+        self.on, self.noise = bool(on), bool(on if graph_noise is None else graph_noise)
+
+    def __enter__(self):
+        global FIXED_WIDTH, GRAPH_NOISE
+        self.prev = (FIXED_WIDTH, GRAPH_NOISE)
+        FIXED_WIDTH, GRAPH_NOISE = self.on, self.noise
+        return self
+
+    def __exit__(self, *exc):
+        global FIXED_WIDTH, GRAPH_NOISE
+        FIXED_WIDTH, GRAPH_NOISE = self.prev
+
 
 class packed_rows:
     """with ops.packed_rows(True): ...  switches the packed execution of Encoder / Decoder stacks on."""
@@ -907,6 +933,9 @@ class GumbelSoftmaxFn(torch.autograd.Function):
         if E is not None:
             if E.shape != logits.shape:
                 raise _lib.NastHipError("noise tensor must have the shape of logits")
+            er, _ = rows_of(E)
+        elif not noise_off and GRAPH_NOISE:
+            E = torch.empty_like(logits, memory_format=torch.contiguous_format).exponential_()     # utils/gumbel.py:28
             er, _ = rows_of(E)
         elif not noise_off:
             gen = torch.cuda.default_generators[logits.device.index]

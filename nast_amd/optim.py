@@ -26,6 +26,27 @@ class FusedAdam(optim.Adam):
             raise NotImplementedError("FusedAdam: amsgrad / maximize / capturable / differentiable are not supported")
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._tables = {}
+        self._dev_step = None       # float64 [1] on the device: the common step count, kept for HIP-graph replays
+
+    # -- step count on the device (nast_amd/graph.py) ------------------------------------------
+    def device_step_counter(self):
+        """The optimizer's step count as a device tensor, created on first use.  A captured step reads its bias corrections
+        from it (1 - beta ** step is computed on the device, in float64 like the host computes it) and increments it, so a
+        replay advances Adam without the host; eager steps keep it in line.  Requires one common count for all parameters."""
+        if self._dev_step is None:
+            counts = {float(st["step"]) for st in self.state.values() if "step" in st}
+            if len(counts) > 1:
+                raise NotImplementedError("FusedAdam: parameters with different step counts cannot share a captured step")
+            p0 = self.param_groups[0]["params"][0]
+            self._dev_step = torch.full((1,), counts.pop() if counts else 0.0, dtype=torch.float64, device=p0.device)
+        return self._dev_step
+
+    def note_replayed_step(self):
+        """Host-side bookkeeping after a graph replay ran one optimizer step on the device: the per-parameter `step`
+        entries of state_dict() (CPU tensors, torch.optim.Adam's layout)."""
+        steps = [st["step"] for st in self.state.values() if "step" in st]
+        if steps:
+            torch._foreach_add_(steps, 1.0)
 
     def zero_grad(self, set_to_none=True):
         """set_to_none=False (what the in-place gradient kernels need) zeroes every buffer in a few multi-tensor launches
@@ -60,9 +81,11 @@ class FusedAdam(optim.Adam):
         return ent
 
     @torch.no_grad()
-    def clip_and_step(self, max_norm=None):
+    def clip_and_step(self, max_norm=None, capturing=False):
         """clip_grad_norm_(all parameters of the optimizer, max_norm) (skipped when None), then Adam.  Returns the
-        total gradient norm as a 0-d device tensor (None without clipping)."""
+        total gradient norm as a 0-d device tensor (None without clipping).
+        capturing=True (under HIP-graph capture): the bias corrections come from the device step counter, which the
+        captured work increments; the host-side counts are left to note_replayed_step()."""
         plists = [[p for p in g["params"] if p.grad is not None] for g in self.param_groups]
         flat = [p for pl in plists for p in pl]
         if not flat:
@@ -99,15 +122,30 @@ class FusedAdam(optim.Adam):
             by_step = {}
             for p in pl:
                 by_step.setdefault(float(self.state[p]["step"]), []).append(p)
+            b1, b2 = g["betas"]
+            if capturing:
+                if len(by_step) != 1 or len([x for x in tabs if x is not None]) != 1:
+                    raise NotImplementedError("FusedAdam: a captured step needs one parameter group with one step count")
+                ds = self.device_step_counter()
+                ds.add_(1.0)
+                bias = torch.cat((1.0 - torch.pow(b1, ds), 1.0 - torch.pow(b2, ds))).float()
+                _, ptrs, sizes, _, (ct, co, nc) = t
+                ops.call("nast_multi_adam_f32", ptrs[0].data_ptr(), ptrs[1].data_ptr(), ptrs[2].data_ptr(), ptrs[3].data_ptr(),
+                         sizes.data_ptr(), sizes.numel(), sq.data_ptr() if sq is not None else None,
+                         float(max_norm) if max_norm is not None else 0.0, float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                         float(g["weight_decay"]), 1.0, 1.0, bias.data_ptr(), ct.data_ptr(), co.data_ptr(), nc, self.CHUNK, stream)
+                self._capture_keepalive = bias
+                continue
+            if self._dev_step is not None and gi == 0:
+                self._dev_step.add_(1.0)
             for si, (step0, sub) in enumerate(sorted(by_step.items())):
                 step = step0 + 1
                 for p in sub:
                     self.state[p]["step"] += 1
-                b1, b2 = g["betas"]
                 _, ptrs, sizes, _, (ct, co, nc) = t if len(by_step) == 1 else self._table((gi, "step", si), g, sub)
                 ops.call("nast_multi_adam_f32", ptrs[0].data_ptr(), ptrs[1].data_ptr(), ptrs[2].data_ptr(), ptrs[3].data_ptr(),
                          sizes.data_ptr(), sizes.numel(), sq.data_ptr() if sq is not None else None,
                          float(max_norm) if max_norm is not None else 0.0, float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-                         float(g["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, ct.data_ptr(), co.data_ptr(), nc, self.CHUNK,
-                         stream)
+                         float(g["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, None, ct.data_ptr(), co.data_ptr(), nc,
+                         self.CHUNK, stream)
         return sq.sqrt().reshape(()) if sq is not None else None

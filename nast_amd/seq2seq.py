@@ -259,12 +259,26 @@ class Seq2seq(BaseModel):
     pack_rows = True            # Encoder / Decoder stacks of the training steps run on the real (unpadded) rows only
     pack_min_tokens = 4096      # ... when the step is GPU-bound (below, the index bookkeeping costs more host time than it saves)
 
+    # HIP-graph replay of f_step (nast_amd/graph.py) for batches below `pack_min_tokens`, where the step is bound by the
+    # host's launch rate (~2000 launches): after `StepGraphs.WARM` eager steps of a given (batch size, temperature,
+    # cyc_rec_enable, use_inference_z) the step is captured once and replayed.  Off by default: the replayed step runs at
+    # fixed widths and draws its Gumbel noise through torch (ops.FIXED_WIDTH / ops.GRAPH_NOISE), so the random stream
+    # differs from the eager step's; single process only.
+    graph_steps = False
+    graph_overlap = True        # record the two-stream form of the step: the graph gets two parallel branches
+    _graphs = None
+
     def f_step(self, incoming, temperature, cyc_rec_enable=True, *, use_inference_z):
         """seq2seq.py:416-543 -> (slf, cyc, adv, slf_len, cyc_len, slf_gen_err, cyc_gen_err) as Python floats."""
+        if self.graph_steps and incoming.data.sent.is_cuda and incoming.data.sent.shape[0] * self.args.max_length < self.pack_min_tokens:
+            if self._graphs is None:
+                from .graph import StepGraphs
+                self._graphs = StepGraphs(self)
+            return self._graphs.f_step(incoming, temperature, cyc_rec_enable, use_inference_z)
         with ops.packed_rows(self.pack_rows and incoming.data.sent.numel() >= self.pack_min_tokens):
             out = self._f_step(incoming, temperature, cyc_rec_enable, use_inference_z=use_inference_z)
             ops.check_packed()       # (the step has just synchronised for its loss values)
-            return out
+            return tuple(item(x) for x in out)
 
     def d_step(self, incoming, temperature, *, use_inference_z):
         """seq2seq.py:551-642 -> adv_loss (float)"""
@@ -273,7 +287,9 @@ class Seq2seq(BaseModel):
             ops.check_packed()
             return out
 
-    def _f_step(self, incoming, temperature, cyc_rec_enable=True, *, use_inference_z):
+    def _f_step(self, incoming, temperature, cyc_rec_enable=True, *, use_inference_z, capturing=False):
+        """-> the seven results as 0-d device tensors (None where the reference reports 0); f_step reads them back.
+        capturing=True: issued under HIP-graph capture (single stream, Adam's step count on the device)."""
         self.net.model_D.eval()
         dm = self.param.volatile.dm
         pad_idx, eos_idx = dm.pad_id, dm.eos_id
@@ -299,7 +315,8 @@ class Seq2seq(BaseModel):
         # self-reconstruction pass produces (backward #1 only adds to .grad): they go to a second HIP stream; the streams are
         # ordered both ways before backward #2 and joined after it.  (Small batches are bound by the host launch rate, where a
         # second stream only adds synchronisation: measured 33 -> 37 ms at 64 sentences.)
-        overlap = self.overlap_passes and cyc_rec_enable and inp_tokens.is_cuda and inp_tokens.numel() >= self._overlap_threshold()
+        overlap = self.overlap_passes and cyc_rec_enable and inp_tokens.is_cuda and inp_tokens.numel() >= self._overlap_threshold() \
+            and (not capturing or self.graph_overlap)
 
         def self_pass():
             """self-reconstruction pass: forward + backward #1 (seq2seq.py:440-464)"""
@@ -324,9 +341,9 @@ class Seq2seq(BaseModel):
         if not cyc_rec_enable:                                                 # seq2seq.py:471-474 (no clipping here)
             slf_rec_loss, slf_rec_length_loss, slf_gen_error = self_pass()
             self.reducer_F.finish()
-            self.optimizer_F.clip_and_step(None)
+            self.optimizer_F.clip_and_step(None, capturing=capturing)
             self.net.model_D.train()
-            return slf_rec_loss.item(), 0, 0, item(slf_rec_length_loss), 0, item(slf_gen_error), 0
+            return slf_rec_loss, None, None, slf_rec_length_loss, None, slf_gen_error, None
 
         def transfer_pass():
             glp, glen, _, _, _ = model_F(
@@ -401,7 +418,9 @@ class Seq2seq(BaseModel):
             side.wait_stream(main)
         else:
             slf_rec_loss, slf_rec_length_loss, slf_gen_error = self_pass()
-            total, cyc_rec_loss, cyc_rec_length_loss, cyc_gen_error, adv_loss = cycle_forward()
+            # fixed-width execution: the decode runs all its steps without the early-exit read-backs
+            with (ops.async_decode(None) if ops.FIXED_WIDTH else contextlib.nullcontext()):
+                total, cyc_rec_loss, cyc_rec_length_loss, cyc_gen_error, adv_loss = cycle_forward()
 
         self.reducer_F.arm("f_full", streams=(main, side) if overlap else ())
         total.backward()
@@ -413,11 +432,10 @@ class Seq2seq(BaseModel):
             main.wait_stream(side)
         self.reducer_F.finish()
 
-        self.last_grad_norm = self.optimizer_F.clip_and_step(5)                # seq2seq.py:536-537
+        self.last_grad_norm = self.optimizer_F.clip_and_step(5, capturing=capturing)                # seq2seq.py:536-537
         self.net.model_D.train()
 
-        return slf_rec_loss.item(), cyc_rec_loss.item(), adv_loss.item(), \
-            item(slf_rec_length_loss), item(cyc_rec_length_loss), item(slf_gen_error), item(cyc_gen_error)
+        return slf_rec_loss, cyc_rec_loss, adv_loss, slf_rec_length_loss, cyc_rec_length_loss, slf_gen_error, cyc_gen_error
 
     def _d_step(self, incoming, temperature, *, use_inference_z):
         dm = self.param.volatile.dm

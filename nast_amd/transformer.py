@@ -333,7 +333,7 @@ class StyleTransformer(nn.Module):
         (what seq2seq.py:453 / :504 compute from the log-probs), without materialising their gradient."""
         batch_size = inp_tokens.size(0)
         max_enc_len = inp_tokens.size(1)
-        if self.check_lengths:
+        if self.check_lengths and not ops.FIXED_WIDTH:
             assert torch.max(inp_lengths) <= inp_tokens.shape[1]
         assert max_enc_len <= self.max_length
 
@@ -604,7 +604,7 @@ class LengthPredictor(nn.Module):
 
         if target_token is not None:
             if not use_inference_z:                                           # :480-484
-                assert (origin_length == target_length).sum() == batch_size
+                assert ops.FIXED_WIDTH or (origin_length == target_length).sum() == batch_size    # (a device read)
                 z = torch.zeros(1, dtype=torch.float, device=dev)[0]
                 return origin_input, target_length, z, z.clone()
             allpos = self.match(origin_token, origin_length, target_token, target_length, embed, origin_soft_rows)
@@ -654,6 +654,8 @@ class LengthPredictor(nn.Module):
             allpos = allpos_buf[:, :steps + 1].contiguous()
         dec_input = ops.lp_gather(origin_input, origin_length, allpos, eos_embed, unk_embed, None, 0, True)   # :576-578
         target_length = (allpos < (origin_length + 1).unsqueeze(-1)).sum(dim=1) - 1                  # :580
+        if ops.FIXED_WIDTH:          # graph replay: all max_length + 1 positions stay, the lengths mask the rest
+            return dec_input, target_length, allpos
         # one device-to-host read for the width (the reference's .max(), :582) and the total (packed rows downstream)
         t_max, t_sum = torch.stack((target_length.max(), target_length.sum())).tolist()
         ops.set_total(target_length, t_sum)
