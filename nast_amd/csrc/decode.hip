@@ -92,6 +92,10 @@ extern "C" int64_t nast_lp_decode_workspace_bytes(int B, int S1, int d, int dff,
   return (int64_t)carve(nullptr, B, S1, d, dff, L, nlayers, 64).total;
 }
 
+bool nast_lp_decode_fused_eligible(const nast_lp_decode_args* A);                                        // decode_fused.hip
+int nast_lp_decode_fused_launch(const nast_lp_decode_args* A, const float* cand, const float* KC, const float* kunk, const float* mk,
+                                const float* mv, float* kc, float* vc, int* steps_dev, hipStream_t s);
+
 #define TRY(expr)            \
   do {                       \
     int rc_ = (expr);        \
@@ -116,9 +120,12 @@ static int lp_decode_impl(const nast_lp_decode_args* A, float* workspace, int* s
   const float scale = 1.0f / sqrtf((float)(d / h));
   const bool fuse_ln = (B <= 1024 && d <= 256 && (d & 3) == 0);
 
+  // one kernel for the whole loop when the model has the shape it is built for (decode_fused.hip); else step by step
+  const bool fused = nast_lp_decode_fused_eligible(A) && (reinterpret_cast<uintptr_t>(A->eos) & 15) == 0;
   hipLaunchKernelGGL(lp_candidates_kernel, dim3(((int64_t)B * NC + 3) / 4), dim3(256), 0, s, A->memory, A->origin_length, A->eos,
                      w.cand, w.mask, B, S1, d);
-  hipLaunchKernelGGL(lp_init_kernel, dim3(B), dim3(256), 0, s, A->memory, A->pos_w, w.x, w.now_pos, A->allpos, B, S1, d, L + 1);
+  if (!fused)
+    hipLaunchKernelGGL(lp_init_kernel, dim3(B), dim3(256), 0, s, A->memory, A->pos_w, w.x, w.now_pos, A->allpos, B, S1, d, L + 1);
   NAST_CHECK_LAUNCH("nast_lp_decode_f32(init)");
   {   // wk(candidates), wk(unk), cross-attention K/V of every layer: grouped launches
     nast_gemm_desc g[NAST_GEMM_MAX_GROUP];     // (fixed array: the call makes no host or device allocation)
@@ -136,6 +143,18 @@ static int lp_decode_impl(const nast_lp_decode_args* A, float* workspace, int* s
         ng = 0;
       }
     }
+  }
+  if (fused) {
+    TRY(nast_lp_decode_fused_launch(A, w.cand, w.KC, w.kunk, w.mk, w.mv, w.kc, w.vc, early_exit ? w.done : nullptr, s));
+    int steps = L;
+    if (early_exit) {   // the reference's early exit, read off the finished table (one read-back, as the loop's last one)
+      if (hipMemcpyAsync(&steps, w.done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        nast_set_error("nast_lp_decode_f32: step-count readback failed: %s", hipGetErrorString(hipGetLastError()));
+        return NAST_ELAUNCH;
+      }
+    }
+    *steps_out = steps;
+    return NAST_OK;
   }
   float* mean = w.stat;          // scratch for the un-fused LayerNorm path
   float* x = w.x;
