@@ -334,15 +334,15 @@ def main():
                                  "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2)}
             roofline["hbm_bound_kernels"] = hbm
             # HBM-side bytes per launch of the same kernel family from the committed PMC passes (tools/pmc_traffic.py,
-            # profiles/r1_pmc_traffic.txt: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections of the microarchitecture guide)
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+            # profiles/r2_pmc_traffic.txt: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections of the microarchitecture guide)
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
             if B == 512 and learnable and os.path.exists(tpath):
                 with open(tpath) as f:
                     t = json.load(f)
                 fams = [t[k] for k in ("nast_gemm_f32_kernel",) if k in t]
                 if fams:
                     roofline["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
-                    roofline["traffic_unit"] = "bytes per launch, PMC passes recorded in profiles/r1_pmc_traffic.txt"
+                    roofline["traffic_unit"] = "bytes per launch, PMC passes recorded in profiles/r2_pmc_traffic.txt"
                 for name, keys in (("vocab_row_kernels", ("nast_log_softmax_fwd_rr_kernel", "nast_softmax_bwd_rr_kernel", "nast_nll_log_softmax_bwd_kernel",
                                                           "nast_gumbel_softmax_fwd_rr_kernel")),):
                     fams = [t[k] for k in keys if k in t]
