@@ -1,5 +1,8 @@
 """BaseModel: the slice of utils/model_helper.py:17-101 the training step depends on (counters, device
-placement).  Checkpoint rotation / annealing helpers are out of scope."""
+placement, `args.restore` of a checkpoint FILE).  Checkpoint rotation (the manager's "last" / "best" names), URL
+downloads and annealing helpers are out of scope."""
+import os
+
 import torch
 
 
@@ -14,7 +17,30 @@ class BaseModel:
         self.checkpoint_manager = checkpoint_manager
         if args.cuda is True:
             raise RuntimeError("Please use cuda or cpu for args.cuda")
+        if args.get("restore") is not None:
+            self.restore(args.restore)                       # model_helper.py:53-88
         self.net = self.net.to(args.cuda)
+
+    def restore(self, path):
+        """`args.restore` (model_helper.py:53-88) for a checkpoint file: counters, weights, and -- with
+        `args.restore_optimizer` -- the optimizer states, from the dictionary `save_checkpoint` writes (the reference's layout:
+        now_batch / now_epoch / weights / one entry per optimizer).  The file is read with `weights_only=True` (nothing in it
+        is executed); a name the reference's checkpoint manager would resolve ("last", "best", a URL) is not a file here
+        and raises instead of being silently ignored."""
+        if str(path).startswith("http") or not os.path.isfile(path):
+            raise NotImplementedError(f"args.restore={path!r}: only a checkpoint file path is supported on this path "
+                                      "(the checkpoint manager's names and URLs are out of scope, SURVEY 2.1 row 11)")
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        self.now_batch, self.now_epoch = ck["now_batch"], ck["now_epoch"]
+        self.net.load_state_dict(ck["weights"])
+        if self.args.get("restore_optimizer", True):
+            for name, opt in self.optimizerList.items():
+                if name in ck and ck[name].get("state"):
+                    keep = [{k: v for k, v in g.items() if k != "params"} for g in opt.param_groups]
+                    opt.load_state_dict(ck[name])
+                    for g, new in zip(opt.param_groups, keep):        # the run's own hyper-parameters win (:70-77)
+                        g.update(new)
+        return ck
 
     def zero_grad(self):
         for p in self.net.parameters():

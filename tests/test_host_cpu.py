@@ -337,3 +337,35 @@ def test_oracle_sample_skip_follows_softmax():
         assert (freq - p).abs().max() < 5e-3, (freq, p)
         assert freq[p == 0].sum() == 0
     assert O.sample_skip(logits[:1], torch.tensor([0.999999999])).item() == 3
+
+
+def test_restore_from_checkpoint_file(tmp_path):
+    """args.restore (utils/model_helper.py:53-88): a checkpoint file written by save_checkpoint restores counters, weights
+    and optimizer state into a fresh trainer; a manager name / URL raises instead of being ignored."""
+    from helpers import make_param
+    from nast_amd.seq2seq import Seq2seq
+    kw = dict(V=40, d=16, h=2, N=1, L=6, learnable=True)
+    a = Seq2seq(make_param(**kw))
+    a.now_batch, a.now_epoch = 7, 2
+    with torch.no_grad():
+        for p in a.net.parameters():
+            p.add_(0.01)
+    p0 = next(iter(a.net.model_F.parameters()))
+    a.optimizer_F.state[p0] = {"step": torch.tensor(3.0), "exp_avg": torch.full_like(p0, 0.5), "exp_avg_sq": torch.full_like(p0, 0.25)}
+    path = str(tmp_path / "ck.model")
+    a.save_checkpoint(path)
+    pb = make_param(**kw)
+    pb.args.restore = path
+    pb.args.lr_F = 3e-4                                         # the new run's hyper-parameter must survive the restore
+    b = Seq2seq(pb)
+    assert (b.now_batch, b.now_epoch) == (7, 2)
+    for (k, x), (_, y) in zip(a.net.state_dict().items(), b.net.state_dict().items()):
+        assert torch.equal(x, y), k
+    q0 = next(iter(b.net.model_F.parameters()))
+    st = b.optimizer_F.state[q0]
+    assert float(st["step"]) == 3.0 and torch.equal(st["exp_avg"], torch.full_like(q0, 0.5))
+    assert b.optimizer_F.param_groups[0]["lr"] == 3e-4
+    pc = make_param(**kw)
+    pc.args.restore = "last"
+    with pytest.raises(NotImplementedError):
+        Seq2seq(pc)
