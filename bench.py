@@ -282,6 +282,14 @@ def main():
         dtg = graphed(m1, b1, 10)
         also["configs1_simple_L16_bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3)}
         del m1
+        # BASELINE configs[4] (stress shape: V=32000, d=1024, h=16, 8 layers, len<=128, learnable) at 64 sentences
+        cfg4 = dict(V=32000, d=1024, h=16, N=8, L=128, learnable=True)
+        m4 = build_model(cfg4, "cuda")
+        b4 = [synth_incoming(64, 128, 32000, 9000 + i, "cuda") for i in range(2)]
+        dt = timed(lambda i: m4.f_step(b4[i % 2], 1.0, use_inference_z=True), 3)
+        also["configs4_stress_L128_bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3)}
+        del m4, b4
+        torch.cuda.empty_cache()
         if a.precision == "fp32":
             # north_star's bf16 variant: GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 storage + accumulate), same step
             _ops.set_gemm_precision("bf16")

@@ -331,7 +331,7 @@ extern "C" int nast_mha_bwd_f32(const float* q, const float* k, const float* v, 
 // ---- packed ("varlen") rows -------------------------------------------------------------------------------------
 // Sentence b owns rows q_off[b] .. q_off[b] + q_len[b] - 1 of q / out / dq and k_off[b] .. + k_len[b] - 1 of k / v / dk / dv
 // (row pitch ld*, heads side by side in a row).  Every key of a sentence is visible to every query of it: the padding
-// that a [B, n, d] batch carries and masks simply does not exist.  max_nq / max_nk bound the lengths (<= 64).
+// that a [B, n, d] batch carries and masks simply does not exist.  max_nq / max_nk bound the lengths (<= 144; beyond 64 positions the head size must be 16, 32 or 64).
 extern "C" int nast_mha_fwd_varlen_f32(const float* q, const float* k, const float* v, float* out, float* lse, int B, int h, int max_nq,
                                        int max_nk, int dk, int ldq, int ldk, int ldv, int ldo, const int32_t* q_off,
                                        const int32_t* k_off, const int32_t* q_len, const int32_t* k_len, int causal, int q_total,
@@ -340,12 +340,12 @@ extern "C" int nast_mha_fwd_varlen_f32(const float* q, const float* k, const flo
   if (rc) return rc;
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(q && k && v && out && lse && q_off && k_off && q_len && k_len, "nast_mha_fwd_varlen_f32: NULL pointer");
-  NAST_REQUIRE(max_nq <= 64 && max_nk <= 64, "nast_mha_fwd_varlen_f32: lengths up to 64 (got %d, %d)", max_nq, max_nk);
+  NAST_REQUIRE(max_nq <= 144 && max_nk <= 144, "nast_mha_fwd_varlen_f32: lengths up to 144 (got %d, %d)", max_nq, max_nk);
   NAST_REQUIRE(q_total >= 0 && q_alloc >= q_total && k_total >= 0 && k_alloc >= k_total, "nast_mha_fwd_varlen_f32: row counts");
   NAST_REQUIRE(((ldq | ldk | ldv | ldo) & 3) == 0, "nast_mha_fwd_varlen_f32: row pitches must be multiples of 4");
   rc = nast_mha_fwd_mfma(q, k, v, nullptr, out, lse, B, h, max_nq, max_nk, dk, ldq, ldk, ldv, ldo, 0, 0, 0, 0, 0, 0, scale,
                          (hipStream_t)stream, q_off, k_off, q_len, k_len, causal, q_total, q_alloc, k_total, k_alloc);
-  NAST_REQUIRE(rc == 0, "nast_mha_fwd_varlen_f32: head size %d not supported", dk);
+  NAST_REQUIRE(rc == 0, "nast_mha_fwd_varlen_f32: head size %d not supported at these lengths (8 needs <= 64 positions)", dk);
   NAST_CHECK_LAUNCH("nast_mha_fwd_varlen_f32");
   return NAST_OK;
 }
@@ -359,12 +359,12 @@ extern "C" int nast_mha_bwd_varlen_f32(const float* q, const float* k, const flo
   if (rc) return rc;
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(q && k && v && dout && lse && dq && dk_ && dv && q_off && k_off && q_len && k_len, "nast_mha_bwd_varlen_f32: NULL pointer");
-  NAST_REQUIRE(max_nq <= 64 && max_nk <= 64, "nast_mha_bwd_varlen_f32: lengths up to 64 (got %d, %d)", max_nq, max_nk);
+  NAST_REQUIRE(max_nq <= 144 && max_nk <= 144, "nast_mha_bwd_varlen_f32: lengths up to 144 (got %d, %d)", max_nq, max_nk);
   NAST_REQUIRE(q_total >= 0 && q_alloc >= q_total && k_total >= 0 && k_alloc >= k_total, "nast_mha_bwd_varlen_f32: row counts");
   NAST_REQUIRE(((ldq | ldk | ldv | ldo) & 3) == 0, "nast_mha_bwd_varlen_f32: row pitches must be multiples of 4");
   rc = nast_mha_bwd_mfma(q, k, v, nullptr, dout, lse, dq, dk_, dv, B, h, max_nq, max_nk, dk, ldq, ldk, ldv, ldo, 0, 0, 0, 0, 0, 0, scale,
                          (hipStream_t)stream, q_off, k_off, q_len, k_len, causal, q_total, q_alloc, k_total, k_alloc);
-  NAST_REQUIRE(rc == 0, "nast_mha_bwd_varlen_f32: head size %d not supported", dk);
+  NAST_REQUIRE(rc == 0, "nast_mha_bwd_varlen_f32: head size %d not supported at these lengths (8 needs <= 64 positions)", dk);
   NAST_CHECK_LAUNCH("nast_mha_bwd_varlen_f32");
   return NAST_OK;
 }

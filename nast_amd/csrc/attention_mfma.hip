@@ -17,7 +17,8 @@
 // dK / dV need lane = key, so S and dP are recomputed with the operands swapped (A = Q / dO rows, B = K / V rows)
 // instead of transposing the score tiles: 7 small products per (sentence, head), all on MFMA.
 //
-// Limits: nq, nk <= 64 and dk in {8, 16, 32, 64}; longer sequences use the LDS kernels in attention.hip.
+// Limits: nq, nk <= 64 and dk in {8, 16, 32, 64}; 65 .. 144 positions (dk 16 / 32 / 64) take the *_long kernels further down;
+// anything else uses the LDS VALU kernels in attention.hip.
 #include <type_traits>
 
 #include "common.h"
@@ -669,6 +670,363 @@ __global__ __launch_bounds__(256) void nast_mha_fwd_wave_kernel(const AttnArgs P
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// Sequences of 65 .. 144 positions (BASELINE configs[4]: max_length 128 -> 129 / 130 rows per sentence).  Same products and
+// the same transposed-score orientation as the kernels above, with what does not scale to 9 key tiles replaced:
+//   * masks are evaluated per element (a dead byte per key in LDS for key-padding masks and sequence ends, the caller's
+//     byte for [n, n] masks, an index compare for the causal flag) instead of 64-bit rows built with ballots;
+//   * backward: K and V stay in LDS for the whole workgroup (78 KB at d_k = 64), Q and dO pass through in blocks of 64
+//     queries (35 KB); dK / dV accumulators of a wavefront's (up to 3) key tiles live in registers across the blocks.
+//     Per block: phase 1 (lane = query) writes the block's dQ rows and delta, phase 2 (lane = key) adds the block to dK / dV;
+//   * every loop over key tiles is cut at the sentence's own length (uniform per workgroup), so packed rows pay for their
+//     real lengths.
+// One workgroup per (sentence, head); forward 2 workgroups per CU, backward 1 (114 KB of LDS).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LONG_NT = 9;
+
+template <int DK>
+__device__ __forceinline__ void stage_block(float* __restrict__ dst, const float* __restrict__ src, int64_t ld, int row0, int rows,
+                                            int rows_pad) {
+  constexpr int LD = DK + 4, V4 = DK / 4;
+  for (int c = threadIdx.x; c < rows_pad * V4; c += 256) {
+    const int r = c / V4, q = (c % V4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < rows) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + r) * ld + q);
+    *reinterpret_cast<float4*>(dst + r * LD + q) = v;
+  }
+}
+
+// dead byte per key: past the sentence, or hidden by a key-padding mask (mask_qs == 0)
+__device__ __forceinline__ void stage_kdead(uint8_t* __restrict__ kdead, const AttnArgs& P, int b, int nk, int keys_pad) {
+  const bool pad_mask = P.mask != nullptr && P.mask_qs == 0;
+  for (int j = threadIdx.x; j < keys_pad; j += 256) kdead[j] = (j >= nk || (pad_mask && P.mask[b * P.mask_bs + j] != 0)) ? 1 : 0;
+}
+
+template <int DK, int NT>
+__global__ __launch_bounds__(256) void nast_mha_fwd_long_kernel(const AttnArgs P) {
+  constexpr int NS = DK / 4, NCT = (DK + 15) / 16, LD = DK + 4;
+  __shared__ __attribute__((aligned(16))) float Ks[NT * 16 * LD];
+  __shared__ __attribute__((aligned(16))) float Vs[NT * 16 * LD];
+  __shared__ __attribute__((aligned(16))) uint8_t kdead[NT * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r15 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x;
+  const int b = bh / P.h, head = bh % P.h;
+  const SeqGeom G = seq_geom(P, b);
+  const int nq = G.nq, nk = G.nk;
+  if (b == 0 && P.q_off != nullptr) zero_pad_rows<DK>(P.out, P.ldo, head, P.q_total, P.q_alloc, threadIdx.x, 256);
+  if (nq <= 0 || nk <= 0) return;               // (uniform for the workgroup)
+  const float* Qb = P.q + G.q0 + head * DK;
+  float* Ob = P.out + G.o0 + head * DK;
+  const int nqt = (nq + 15) / 16, nkt = (nk + 15) / 16;
+  const bool row_mask = P.mask != nullptr && P.mask_qs != 0;
+  stage_block<DK>(Ks, P.k + G.k0 + head * DK, P.ldk, 0, nk, nkt * 16);
+  stage_block<DK>(Vs, P.v + G.v0 + head * DK, P.ldv, 0, nk, nkt * 16);
+  stage_kdead(kdead, P, b, nk, NT * 16);
+  __syncthreads();
+  for (int it = wave; it < nqt; it += 4) {
+    const int i = 16 * it + r15;                 // this lane's query
+    const int ic = i < nq ? i : nq - 1;
+    float qf[NS];
+    load_frag<DK>(qf, Qb + (int64_t)ic * P.ldq, g);
+    const uint8_t* mrow = row_mask ? P.mask + b * P.mask_bs + (int64_t)ic * P.mask_qs : nullptr;
+    f32x4 st[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      st[jt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (jt < nkt) {
+        float kf[NS];
+        lds_frag<DK>(kf, Ks + (16 * jt + r15) * LD, g);
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a = mfma4(kf[s], qf[s], a);
+        const uint32_t kd = *reinterpret_cast<const uint32_t*>(&kdead[16 * jt + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * jt + 4 * g + r;
+          const bool dead = ((kd >> (8 * r)) & 0xffu) != 0 || (mrow != nullptr && mrow[j < nk ? j : 0] != 0) || (P.causal && j > i);
+          const float sc = dead ? -INFINITY : a[r] * P.scale;
+          st[jt][r] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      }
+    }
+    mx = xor_max_g(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+      if (jt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(st[jt][r] - mx);
+          st[jt][r] = e;
+          sum += e;
+        }
+      }
+    sum = xor_sum_g(sum);
+    const float inv = 1.f / sum;
+    if (g == 0 && i < nq) P.lse[(int64_t)bh * P.nq + i] = mx + __logf(sum);
+    f32x4 o[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+      if (jt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* vr = Vs + (16 * jt + 4 * g + r) * LD;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) o[ct] = mfma4(st[jt][r], vr[16 * ct + r15], o[ct]);
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int io = 16 * it + 4 * g + r;
+      const float invr = __shfl(inv, 4 * g + r, 64);
+      if (io < nq) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) Ob[(int64_t)io * P.ldo + 16 * ct + r15] = o[ct][r] * invr;
+      }
+    }
+  }
+}
+
+template <int DK, int NT>
+__global__ __launch_bounds__(256, 1) void nast_mha_bwd_long_kernel(const AttnArgs P) {
+  constexpr int NS = DK / 4, NCT = (DK + 15) / 16, LD = DK + 4, QB = 4, KU = (NT + 3) / 4;
+  __shared__ __attribute__((aligned(16))) float Ks[NT * 16 * LD];
+  __shared__ __attribute__((aligned(16))) float Vs[NT * 16 * LD];
+  __shared__ __attribute__((aligned(16))) float Qs[QB * 16 * LD];
+  __shared__ __attribute__((aligned(16))) float Gs[QB * 16 * LD];
+  __shared__ __attribute__((aligned(16))) float dlt[QB * 16];
+  __shared__ __attribute__((aligned(16))) float lse_s[QB * 16];
+  __shared__ __attribute__((aligned(16))) uint8_t kdead[NT * 16];
+  __shared__ int live_q[QB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r15 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x;
+  const int b = bh / P.h, head = bh % P.h;
+  const SeqGeom G = seq_geom(P, b);
+  const int nq = G.nq, nk = G.nk;
+  if (b == 0 && P.q_off != nullptr) {
+    zero_pad_rows<DK>(P.dq, P.ldq, head, P.q_total, P.q_alloc, threadIdx.x, 256);
+    zero_pad_rows<DK>(P.dk, P.ldk, head, P.k_total, P.k_alloc, threadIdx.x, 256);
+    zero_pad_rows<DK>(P.dv, P.ldv, head, P.k_total, P.k_alloc, threadIdx.x, 256);
+  }
+  if (nq <= 0 || nk <= 0) return;               // (uniform for the workgroup)
+  float* dQb = P.dq + G.q0 + head * DK;
+  float* dKb = P.dk + G.k0 + head * DK;
+  float* dVb = P.dv + G.v0 + head * DK;
+  const float* Qg = P.q + G.q0 + head * DK;
+  const float* Gg = P.dout + G.o0 + head * DK;
+  const float scale = P.scale;
+  const int nqt = (nq + 15) / 16, nkt = (nk + 15) / 16;
+  const bool row_mask = P.mask != nullptr && P.mask_qs != 0;
+  stage_block<DK>(Ks, P.k + G.k0 + head * DK, P.ldk, 0, nk, nkt * 16);
+  stage_block<DK>(Vs, P.v + G.v0 + head * DK, P.ldv, 0, nk, nkt * 16);
+  stage_kdead(kdead, P, b, nk, NT * 16);
+  __syncthreads();
+  // key tiles past the last key any query may see take no part (a key-padding mask hides the sentence tail)
+  int nkt_e = nkt;
+  while (nkt_e > 1) {
+    bool any = false;
+    for (int r = 0; r < 16; ++r) any = any || kdead[16 * (nkt_e - 1) + r] == 0;
+    if (any) break;
+    --nkt_e;
+  }
+  f32x4 accK[KU][NCT], accV[KU][NCT];
+#pragma unroll
+  for (int u = 0; u < KU; ++u)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      accK[u][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accV[u][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  for (int qb = 0; qb * QB < nqt; ++qb) {
+    const int row0 = qb * QB * 16;
+    if (threadIdx.x < QB) live_q[threadIdx.x] = 0;
+    __syncthreads();
+    {
+      constexpr int V4 = DK / 4;
+      for (int c = threadIdx.x; c < QB * 16 * V4; c += 256) {
+        const int r = c / V4, q = (c % V4) * 4;
+        float4 vq = make_float4(0.f, 0.f, 0.f, 0.f), vg = vq;
+        if (row0 + r < nq) {
+          vq = *reinterpret_cast<const float4*>(Qg + (int64_t)(row0 + r) * P.ldq + q);
+          vg = *reinterpret_cast<const float4*>(Gg + (int64_t)(row0 + r) * P.ldo + q);
+        }
+        *reinterpret_cast<float4*>(Qs + r * LD + q) = vq;
+        *reinterpret_cast<float4*>(Gs + r * LD + q) = vg;
+        if (vg.x != 0.f || vg.y != 0.f || vg.z != 0.f || vg.w != 0.f) live_q[r >> 4] = 1;   // benign race: all store 1
+      }
+      for (int r = threadIdx.x; r < QB * 16; r += 256) {
+        const int i = row0 + r;
+        lse_s[r] = P.lse_in[(int64_t)bh * P.nq + (i < nq ? i : nq - 1)];
+        dlt[r] = 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- phase 1: lane = query.  dQ[i][c] = scale * sum_j dS[i][j] K[j][c]; one query tile of the block per wavefront ----
+    {
+      const int itl = wave, it = qb * QB + itl;
+      if (it < nqt) {
+        if (!live_q[itl]) {                        // dO == 0 for the whole tile: dQ rows are zero
+          for (int c = lane; c < 16 * (DK / 4); c += 64) {
+            const int io = 16 * it + c / (DK / 4), q4 = (c % (DK / 4)) * 4;
+            if (io < nq) *reinterpret_cast<float4*>(dQb + (int64_t)io * P.ldq + q4) = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        } else {
+          const int i = 16 * it + r15, ic = i < nq ? i : nq - 1;
+          const uint8_t* mrow = row_mask ? P.mask + b * P.mask_bs + (int64_t)ic * P.mask_qs : nullptr;
+          float qf[NS], gf[NS];
+          lds_frag<DK>(qf, Qs + (16 * itl + r15) * LD, g);
+          lds_frag<DK>(gf, Gs + (16 * itl + r15) * LD, g);
+          const float l = lse_s[16 * itl + r15];
+          f32x4 st[NT], dp[NT];
+          float dsum = 0.f;
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) {
+            st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (jt < nkt_e) {
+              float kf[NS], vf[NS];
+              lds_frag<DK>(kf, Ks + (16 * jt + r15) * LD, g);
+              lds_frag<DK>(vf, Vs + (16 * jt + r15) * LD, g);
+#pragma unroll
+              for (int s = 0; s < NS; ++s) {
+                st[jt] = mfma4(kf[s], qf[s], st[jt]);
+                dp[jt] = mfma4(vf[s], gf[s], dp[jt]);
+              }
+              const uint32_t kd = *reinterpret_cast<const uint32_t*>(&kdead[16 * jt + 4 * g]);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * g + r;
+                const bool dead = i >= nq || ((kd >> (8 * r)) & 0xffu) != 0 || (mrow != nullptr && mrow[j < nk ? j : 0] != 0) ||
+                                  (P.causal && j > i);
+                const float p = dead ? 0.f : __expf(st[jt][r] * scale - l);
+                st[jt][r] = p;
+                dsum = fmaf(p, dp[jt][r], dsum);
+              }
+            }
+          }
+          dsum = xor_sum_g(dsum);
+          if (g == 0) dlt[16 * itl + r15] = dsum;
+          f32x4 acc[NCT];
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+            if (jt < nkt_e) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float ds = st[jt][r] * (dp[jt][r] - dsum) * scale;
+                const float* kr = Ks + (16 * jt + 4 * g + r) * LD;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma4(ds, kr[16 * ct + r15], acc[ct]);
+              }
+            }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int io = 16 * it + 4 * g + r;
+            if (io < nq) {
+#pragma unroll
+              for (int ct = 0; ct < NCT; ++ct) dQb[(int64_t)io * P.ldq + 16 * ct + r15] = acc[ct][r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();   // dlt of the block is read by every wavefront below
+    // ---- phase 2: lane = key.  dK[j][c] += scale * sum_i dS[i][j] Q[i][c],  dV[j][c] += sum_i P[i][j] dO[i][c] ----
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int jt = wave + 4 * u;
+      if (jt < nkt_e) {
+        const int j = 16 * jt + r15;
+        float kf[NS], vf[NS];
+        lds_frag<DK>(kf, Ks + (16 * jt + r15) * LD, g);
+        lds_frag<DK>(vf, Vs + (16 * jt + r15) * LD, g);
+        const bool jdead = kdead[j] != 0;
+#pragma unroll
+        for (int itl = 0; itl < QB; ++itl) {
+          const int it = qb * QB + itl;
+          if (it < nqt && live_q[itl]) {
+            float qf[NS], gf[NS];
+            lds_frag<DK>(qf, Qs + (16 * itl + r15) * LD, g);
+            lds_frag<DK>(gf, Gs + (16 * itl + r15) * LD, g);
+            f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f}, d4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              s4 = mfma4(qf[s], kf[s], s4);
+              d4 = mfma4(gf[s], vf[s], d4);
+            }
+            const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[16 * itl + 4 * g]);
+            const float4 t4 = *reinterpret_cast<const float4*>(&dlt[16 * itl + 4 * g]);
+            const f32x4 lr = {l4.x, l4.y, l4.z, l4.w}, tr = {t4.x, t4.y, t4.z, t4.w};
+            f32x4 p4, ds4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * it + 4 * g + r;
+              const bool dead = jdead || i >= nq || (P.causal && j > i) ||
+                                (row_mask && P.mask[b * P.mask_bs + (int64_t)(i < nq ? i : nq - 1) * P.mask_qs + (j < nk ? j : 0)] != 0);
+              const float p = dead ? 0.f : __expf(s4[r] * scale - lr[r]);
+              p4[r] = p;
+              ds4[r] = p * (d4[r] - tr[r]) * scale;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float* qr = Qs + (16 * itl + 4 * g + r) * LD;
+              const float* gr = Gs + (16 * itl + 4 * g + r) * LD;
+#pragma unroll
+              for (int ct = 0; ct < NCT; ++ct) {
+                accK[u][ct] = mfma4(ds4[r], qr[16 * ct + r15], accK[u][ct]);
+                accV[u][ct] = mfma4(p4[r], gr[16 * ct + r15], accV[u][ct]);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();   // Qs / Gs / dlt are overwritten by the next block
+  }
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+    const int jt = wave + 4 * u;
+    if (jt < nkt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jo = 16 * jt + 4 * g + r;
+        if (jo < nk) {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const bool livet = jt < nkt_e;
+            dKb[(int64_t)jo * P.ldk + 16 * ct + r15] = livet ? accK[u][ct][r] : 0.f;
+            dVb[(int64_t)jo * P.ldv + 16 * ct + r15] = livet ? accV[u][ct][r] : 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int DK>
+int launch_long(const AttnArgs& A, bool bwd, hipStream_t s) {
+  const dim3 grid(A.BH), block(256);
+  if (bwd) hipLaunchKernelGGL((nast_mha_bwd_long_kernel<DK, LONG_NT>), grid, block, 0, s, A);
+  else hipLaunchKernelGGL((nast_mha_fwd_long_kernel<DK, LONG_NT>), grid, block, 0, s, A);
+  return 0;
+}
+static int dispatch_long(const AttnArgs& A, int dk, bool bwd, hipStream_t s) {
+  if (A.nq > 16 * LONG_NT || A.nk > 16 * LONG_NT) return 1;
+  const char* e = getenv("NAST_ATTN_LONG");            // A/B aid: 0 = the LDS VALU kernels of attention.hip (padded batches only)
+  if (e && atoi(e) == 0) return 1;
+  switch (dk) {
+    case 16: return launch_long<16>(A, bwd, s);
+    case 32: return launch_long<32>(A, bwd, s);
+    case 64: return launch_long<64>(A, bwd, s);
+  }
+  return 1;
+}
+
 template <int DK>
 int launch_fwd_nt(const AttnArgs& A, int nkt, hipStream_t s) {
   const dim3 grid((A.BH + 3) / 4), block(256);
@@ -699,13 +1057,13 @@ int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint
                       int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs, int64_t o_bs,
                       int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s, const int32_t* q_off, const int32_t* k_off,
                       const int32_t* q_len, const int32_t* k_len, int causal, int q_total, int q_alloc, int k_total, int k_alloc) {
-  if (nq > 64 || nk > 64) return 1;
   AttnArgs A = {};
   A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len; A.causal = causal;
   A.q_total = q_total; A.q_alloc = q_alloc; A.k_total = k_total; A.k_alloc = k_alloc;
   A.q = q; A.k = k; A.v = v; A.mask = mask; A.out = out; A.lse = lse;
   A.BH = B * h; A.h = h; A.nq = nq; A.nk = nk; A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.ldo = ldo;
   A.q_bs = q_bs; A.k_bs = k_bs; A.v_bs = v_bs; A.o_bs = o_bs; A.mask_bs = mask_bs; A.mask_qs = mask_qs; A.scale = scale;
+  if (nq > 64 || nk > 64) return dispatch_long(A, dk, false, s);
   const int nkt = (nk + 15) / 16;
   switch (dk) {
     case 8: return launch_fwd_nt<8>(A, nkt, s);
@@ -720,13 +1078,13 @@ int nast_mha_bwd_mfma(const float* q, const float* k, const float* v, const uint
                       float* dk_, float* dv, int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs,
                       int64_t k_bs, int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s,
                       const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len, int causal, int q_total, int q_alloc, int k_total, int k_alloc) {
-  if (nq > 64 || nk > 64) return 1;
   AttnArgs A = {};
   A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len; A.causal = causal;
   A.q_total = q_total; A.q_alloc = q_alloc; A.k_total = k_total; A.k_alloc = k_alloc;
   A.q = q; A.k = k; A.v = v; A.mask = mask; A.dout = dout; A.lse_in = lse; A.dq = dq; A.dk = dk_; A.dv = dv;
   A.BH = B * h; A.h = h; A.nq = nq; A.nk = nk; A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.ldo = ldo;
   A.q_bs = q_bs; A.k_bs = k_bs; A.v_bs = v_bs; A.o_bs = o_bs; A.mask_bs = mask_bs; A.mask_qs = mask_qs; A.scale = scale;
+  if (nq > 64 || nk > 64) return dispatch_long(A, dk, true, s);
   const int nt = ((nq > nk ? nq : nk) + 15) / 16;
   switch (dk) {
     case 8: return launch_bwd_nt<8>(A, nt, s);

@@ -466,7 +466,12 @@ def run_deferred():
 # real rows are the padded computation's; padded rows come back as zeros.  Enabled by Seq2seq for its training steps
 # (PACK_ROWS); module-level calls keep the reference's padded behaviour, including the values at padded positions.
 PACK_ROWS = False
-PACK_MAX_LEN = 64            # limit of the packed attention kernels
+PACK_MAX_LEN = 64            # limit of the packed attention kernels for any head size ...
+PACK_MAX_LEN_LONG = 144      # ... and for head sizes 16 / 32 / 64 (the *_long kernels of attention_mfma.hip)
+
+
+def pack_len_ok(width, dk):
+    return width <= PACK_MAX_LEN or (width <= PACK_MAX_LEN_LONG and dk in (16, 32, 64))
 
 # Fixed-shape execution (nast_amd/graph.py: HIP-graph replay of a training step).  The step normally trims tensors to the
 # longest sentence of the batch -- NoiseLayer's output, the generated sentences -- which costs a device-to-host read each and
@@ -619,15 +624,16 @@ class PackedSoft:
         return unpack_rows(self.rows.detach()[:, j:j + 1], self.ps).squeeze(-1)
 
 
-def packed_of(mask, x):
-    """PackedSeq for a padding mask made by transformer._pad_mask, or None when packing does not apply."""
+def packed_of(mask, x, dk=None):
+    """PackedSeq for a padding mask made by transformer._pad_mask, or None when packing does not apply.
+    dk = head size of the attention that will read the rows (decides the length limit)."""
     if not PACK_ROWS or mask is None or not x.is_cuda:
         return None
     ps = getattr(mask, "nast_packed", None)
     if ps is not None:
         return ps
     src = getattr(mask, "nast_lengths", None)
-    if src is None or mask.shape[-1] > PACK_MAX_LEN:
+    if src is None or not pack_len_ok(mask.shape[-1], dk):
         return None
     lengths, extra = src
     total = getattr(lengths, "nast_total", None)

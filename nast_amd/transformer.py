@@ -197,7 +197,7 @@ class Encoder(nn.Module):
     def forward(self, x, mask, rows=None):
         """transformer.py:163-171.  rows=(grp, grp_stride, grp_off, rows_out): normalise only those rows."""
         assert x.size(1) == mask.size(-1)
-        ps = ops.packed_of(mask, x)
+        ps = ops.packed_of(mask, x, x.shape[-1] // self.layers[0].self_attn.h)
         if ps is not None and (rows is None or (rows[0] == 1 and rows[2] == 0)):
             # packed rows: only the real tokens of every sentence go through the layers
             y = ops.pack_rows(x, ps)
@@ -240,7 +240,8 @@ class Decoder(nn.Module):
         (what StyleTransformer keeps, transformer.py:103) without computing row 0; with nll_targets [B, n-1]
         the per-token negative log-likelihood of those tokens is returned instead of the log-probs."""
         assert x.size(1) == tgt_mask.size(-1)
-        pt, pm = ops.packed_of(tgt_mask, x), ops.packed_of(src_mask, memory)
+        dk = x.shape[-1] // self.layers[0].self_attn.h
+        pt, pm = ops.packed_of(tgt_mask, x, dk), ops.packed_of(src_mask, memory, dk)
         if pt is not None and pm is not None and skip_first:
             return self._forward_packed(x, memory, pt, pm, temperature, nll_targets, packed_out)
         y = x
@@ -422,8 +423,9 @@ class HiddenDecoder(nn.Module):
         sentence b are consumed downstream -- the stack may then run on those rows only (ops.PackedSeq); the other
         positions come back as zeros."""
         assert x.size(1) == tgt_mask.size(-1)
-        pm = ops.packed_of(src_mask, memory) if causal_lengths is not None else None
-        if pm is not None and x.size(1) <= ops.PACK_MAX_LEN:
+        dk = x.shape[-1] // self.layers[0].self_attn.h
+        pm = ops.packed_of(src_mask, memory, dk) if causal_lengths is not None else None
+        if pm is not None and ops.pack_len_ok(x.size(1), dk):
             pt = ops.PackedSeq(causal_lengths, x.size(1))
             y, mem = ops.pack_rows(x, pt), ops.pack_rows(memory, pm)
             self_pair, cross_pair = ops.PackedPair(pt, pt, causal=True), ops.PackedPair(pt, pm)

@@ -167,7 +167,11 @@ def ref_attention(q, k, v, mask, h):
 @pytest.mark.parametrize("B,nq,nk,h,dk,kind", [(3, 7, 9, 4, 8, "pad"), (4, 17, 17, 4, 64, "pad"), (2, 33, 33, 4, 64, "causal"),
                                                 (2, 33, 34, 4, 64, "pad"), (2, 70, 70, 2, 64, "causal"), (1, 130, 130, 2, 64, "pad"),
                                                 (2, 1, 12, 4, 16, "none"), (2, 9, 9, 2, 32, "causal"),
-                                                (2, 40, 20, 4, 16, "pad"), (3, 64, 64, 2, 64, "pad"), (2, 20, 50, 2, 8, "pad"), (2, 48, 49, 2, 32, "none")])
+                                                (2, 40, 20, 4, 16, "pad"), (3, 64, 64, 2, 64, "pad"), (2, 20, 50, 2, 8, "pad"), (2, 48, 49, 2, 32, "none"),
+                                                # 65 .. 144 positions: the *_long kernels (K/V resident, Q/dO in blocks of 64 queries)
+                                                (3, 129, 129, 2, 64, "pad"), (2, 100, 130, 2, 32, "pad"), (2, 80, 80, 2, 16, "causal"),
+                                                (2, 144, 144, 1, 64, "none"), (2, 65, 129, 2, 64, "causal"), (2, 130, 40, 2, 64, "pad"),
+                                                (2, 150, 150, 1, 64, "pad")])
 def test_attention(ops, B, nq, nk, h, dk, kind):
     g = torch.Generator().manual_seed(B * 100 + nq)
     D = h * dk
@@ -190,7 +194,8 @@ def test_attention(ops, B, nq, nk, h, dk, kind):
     relclose(y, yref); relclose(qg.grad, qr.grad); relclose(kg.grad, kr.grad); relclose(vg.grad, vr.grad)
 
 
-@pytest.mark.parametrize("B,n,h,dk,holes", [(6, 33, 4, 64, False), (5, 48, 2, 32, False), (4, 33, 4, 64, True), (3, 20, 4, 16, True)])
+@pytest.mark.parametrize("B,n,h,dk,holes", [(6, 33, 4, 64, False), (5, 48, 2, 32, False), (4, 33, 4, 64, True), (3, 20, 4, 16, True),
+                                            (5, 129, 2, 64, False), (4, 100, 2, 32, True), (3, 144, 1, 16, True)])
 def test_attention_ragged_backward(ops, B, n, h, dk, holes):
     """The backward kernel skips key tiles masked for every query and query tiles whose cotangent rows are all zero
     (what a ragged batch looks like: padded positions carry no loss).  Both short cuts must be exact, also for a key
@@ -500,7 +505,8 @@ def test_fused_adam_matches_torch(ops, max_norm, wd):
         np.testing.assert_allclose(sd_got["state"][k]["exp_avg_sq"].cpu().numpy(), sd_ref["state"][k]["exp_avg_sq"].numpy(), rtol=5e-5, atol=1e-12)
 
 
-@pytest.mark.parametrize("B,nq,nk,h,dk", [(6, 33, 33, 4, 64), (5, 20, 48, 2, 32), (3, 64, 17, 4, 16), (4, 9, 9, 2, 8)])
+@pytest.mark.parametrize("B,nq,nk,h,dk", [(6, 33, 33, 4, 64), (5, 20, 48, 2, 32), (3, 64, 17, 4, 16), (4, 9, 9, 2, 8),
+                                          (5, 129, 129, 2, 64), (4, 70, 130, 2, 32), (3, 144, 90, 2, 16)])
 def test_attention_packed_rows(ops, B, nq, nk, h, dk):
     """nast_mha_*_varlen_f32 on packed rows == the padded call with a key-padding mask, on the real rows (forward and
     all three gradients); sentences of length 1 and of full width included."""
@@ -529,9 +535,10 @@ def test_attention_packed_rows(ops, B, nq, nk, h, dk):
     relclose(ops.unpack_rows(dv, pk), vr.grad * kmask)
 
 
-def test_attention_packed_rows_causal(ops):
+@pytest.mark.parametrize("n,h,dk", [(33, 4, 64), (129, 2, 64), (100, 2, 32)])
+def test_attention_packed_rows_causal(ops, n, h, dk):
     """causal flag of the packed attention entry points == the padded call with the causal mask, on the real rows"""
-    B, n, h, dk = 5, 33, 4, 64
+    B = 5
     g = torch.Generator().manual_seed(5)
     D = h * dk
     ln = torch.randint(1, n + 1, (B,), generator=g); ln[0], ln[-1] = n, 1
