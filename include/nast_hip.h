@@ -111,7 +111,7 @@ int nast_mha_bwd_f32(const float* q, const float* k, const float* v, const uint8
 /* Packed ("varlen") rows -- no counterpart in the reference, which pads every sentence to the batch width and masks
  * (transformer.py:57-63, :296-303): sentence b owns rows q_off[b] .. q_off[b]+q_len[b]-1 of q / out / dq and rows
  * k_off[b] .. +k_len[b]-1 of k / v / dk / dv (row pitch ld*, heads side by side); every key of a sentence is visible to
- * every query of it, i.e. exactly what the padding mask leaves.  max_nq, max_nk <= 64 bound the lengths.
+ * every query of it, i.e. exactly what the padding mask leaves.  max_nq, max_nk bound the lengths: <= 64 for any head size, <= 144 for head sizes 16 / 32 / 64.
  * lse: [B, h, max_nq].  Used by Encoder/Decoder when they run on packed rows. */
 int nast_mha_fwd_varlen_f32(const float* q, const float* k, const float* v, float* out, float* lse, int B, int h,
                             int max_nq, int max_nk, int dk, int ldq, int ldk, int ldv, int ldo,

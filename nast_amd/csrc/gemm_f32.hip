@@ -840,11 +840,12 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
     // measured (tools/gemm_bench, NAST_GEMM_TILE=0/2): the 64x64 tile at 4 workgroups per CU beats 128x128 at 2 on
     // every d_model-sized problem of the step (finer quantisation over 256 CUs, prologue/epilogue of one
     // workgroup hidden behind three others); 128x128 only wins (3-8 %) once there are thousands of tiles
-    int cfg = tilesL >= 4096 ? 2 : 0;
+    static const int t128_min = [] { const char* e = getenv("NAST_GEMM_T128_MIN"); return e ? atoi(e) : 4096; }();   // tuning aid
+    int cfg = tilesL >= t128_min ? 2 : 0;
     if (force >= 0) cfg = force;
     if (cfg == 2) plan_and_launch<128, 128, NAST_BK128>(rest, nrest, stream, false, nullptr);
     else plan_and_launch<64, 64, 32>(rest, nrest, stream, false, nullptr);
-    if (nast_prof_shapes(1)) nast_prof_after(1, stream, flops_of(rest, nrest), signature(tilesL >= 4096 ? "t128" : "t64", rest, nrest).c_str());
+    if (nast_prof_shapes(1)) nast_prof_after(1, stream, flops_of(rest, nrest), signature(cfg == 2 ? "t128" : "t64", rest, nrest).c_str());
     else nast_prof_after(1, stream, flops_of(rest, nrest));
   }
   NAST_CHECK_LAUNCH("nast_gemm_f32");
