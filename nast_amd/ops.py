@@ -120,12 +120,12 @@ def d_fwd(x2, W, y2, bias=None, residual=None, relu=False):
     return desc(x2, W, y2, M, N, K, K, K, N, 0, 1, bias=bias, residual=residual, flags=GEMM_RELU if relu else 0)
 
 
-def d_dgrad(dy2_list, W_list, dx2, relu_src=None):
-    """dx[M,K] = sum_i dy_i[M,N] @ W_i[N,K]"""
+def d_dgrad(dy2_list, W_list, dx2, relu_src=None, accumulate=False):
+    """dx[M,K] (+)= sum_i dy_i[M,N] @ W_i[N,K]"""
     dy0, W0 = dy2_list[0], W_list[0]
     M, N = dy0.shape
     K = W0.shape[1]
-    return desc(list(dy2_list), list(W_list), dx2, M, K, N, N, K, K, 0, 0, relu_src=relu_src)
+    return desc(list(dy2_list), list(W_list), dx2, M, K, N, N, K, K, 0, 0, relu_src=relu_src, flags=GEMM_ACCUM if accumulate else 0)
 
 
 def d_wgrad(dy2, x2, dW, db=None):
@@ -702,14 +702,54 @@ def attention(q, k, v, mask, h):
 # ------------------------------------------------------------------------------------------------
 # ... and fused sublayers (what the Encoder/Decoder layers actually run)
 # ------------------------------------------------------------------------------------------------
+class _KVHolder:
+    """Gradient of one encoder memory tensor, shared by the cross-attention sublayers of all decoder layers that read it."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+class SharedKVFn(torch.autograd.Function):
+    """Identity on the encoder memory that collects its gradient.  Every decoder layer's cross-attention reads the same memory
+    (transformer.py:256), so autograd would receive one [rows, d] gradient per layer and sum them with N - 1 full-size adds
+    (49 per f_step).  Instead the sublayers' dgrad GEMMs write / accumulate (NAST_GEMM_ACCUM epilogue) into ONE buffer kept
+    on the holder and return no gradient of their own; this node runs once all of them have (the autograd engine counts an
+    undefined gradient as a satisfied dependency) and hands the buffer on."""
+
+    @staticmethod
+    def forward(ctx, memory, holder):
+        ctx.holder = holder
+        ctx.set_materialize_grads(False)
+        return memory.view_as(memory)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf, ctx.holder.buf = ctx.holder.buf, None
+        if g is not None:                     # a consumer that is not a cross-attention sublayer
+            buf = g if buf is None else buf.add_(g.reshape(buf.shape))
+        return buf, None
+
+
+def shared_kv(memory):
+    """-> the memory to hand to a stack of decoder layers (see SharedKVFn); the tensor itself when no gradient is needed."""
+    if not (torch.is_grad_enabled() and memory.requires_grad and memory.is_cuda):
+        return memory
+    holder = _KVHolder()
+    m = SharedKVFn.apply(memory, holder)
+    m.nast_kv_holder = holder
+    return m
+
+
 class AttnSublayerFn(torch.autograd.Function):
     """x + fc(MHA(LN(x) Wq, kv Wk, kv Wv))  -- SublayerConnection around MultiHeadAttention
     (transformer.py:324-326 + :284-294).  kv_src None = self-attention on LN(x); otherwise cross-attention
     on `kv_src` (the encoder memory, not normalised, transformer.py:256)."""
 
     @staticmethod
-    def forward(ctx, x, kv_src, mask, h, ln_w, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo):
+    def forward(ctx, x, kv_src, mask, h, ln_w, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo, kv_holder=None):
         _chk(x, kv_src, ln_w, ln_b, Wq, bq, Wk, bk, Wv, bv, Wo, bo)
+        ctx.kv_holder = kv_holder
         packed = isinstance(mask, PackedPair)         # x [Rq, d] (and kv_src [Rk, d]) are packed rows
         d = x.shape[-1]
         x2 = _c(x).view(-1, d)
@@ -762,12 +802,19 @@ class AttnSublayerFn(torch.autograd.Function):
         else:
             descs.append(d_dgrad([dq2], [Wq], dz))
             if ctx.needs_input_grad[1]:
-                dkv = torch.empty_like(kv2)
-                descs.append(d_dgrad([dk2, dv2], [Wk, Wv], dkv))
+                hold = ctx.kv_holder
+                if hold is None:
+                    dkv = torch.empty_like(kv2)
+                    descs.append(d_dgrad([dk2, dv2], [Wk, Wv], dkv))
+                elif hold.buf is None:                     # first layer to run backward: plain store into the shared buffer
+                    hold.buf = torch.empty(ctx.kvshape, device=kv2.device, dtype=F32)
+                    descs.append(d_dgrad([dk2, dv2], [Wk, Wv], hold.buf.view(-1, d)))
+                else:                                      # the others add to it in the GEMM epilogue
+                    descs.append(d_dgrad([dk2, dv2], [Wk, Wv], hold.buf.view(-1, d), accumulate=True))
         gemm(descs)
         dx = ln_bwd(dz, x2, ln_w, mean, rstd, dlnw, dlnb, dx_add=dy2)
         grads_written(ctx.params)
-        return (dx.view(ctx.xshape), dkv.view(ctx.kvshape) if dkv is not None else None, None, None) + tuple(rets)
+        return (dx.view(ctx.xshape), dkv.view(ctx.kvshape) if dkv is not None else None, None, None) + tuple(rets) + (None,)
 
 
 class FFNSublayerFn(torch.autograd.Function):
@@ -808,7 +855,8 @@ class FFNSublayerFn(torch.autograd.Function):
 def attn_sublayer(x, kv_src, mask, h, ln, mha):
     p = mha.head_projs
     return AttnSublayerFn.apply(x, kv_src, mask, h, ln.weight, ln.bias, p[0].weight, p[0].bias, p[1].weight, p[1].bias,
-                                p[2].weight, p[2].bias, mha.fc.weight, mha.fc.bias)
+                                p[2].weight, p[2].bias, mha.fc.weight, mha.fc.bias,
+                                getattr(kv_src, "nast_kv_holder", None) if kv_src is not None else None)
 
 
 def ffn_sublayer(x, ln, ffn):

@@ -245,6 +245,7 @@ class Decoder(nn.Module):
         if pt is not None and pm is not None and skip_first:
             return self._forward_packed(x, memory, pt, pm, temperature, nll_targets, packed_out)
         y = x
+        memory = ops.shared_kv(memory)      # one gradient buffer for all layers' cross-attention (ops.SharedKVFn)
         for layer in self.layers:
             y = layer(y, memory, src_mask, tgt_mask)
         B, n, d = y.shape
@@ -261,6 +262,7 @@ class Decoder(nn.Module):
         B, n, d = x.shape
         y, mem = ops.pack_rows(x, pt), ops.pack_rows(memory, pm)
         self_pair, cross_pair = ops.PackedPair(pt, pt), ops.PackedPair(pt, pm)
+        mem = ops.shared_kv(mem)
         for layer in self.layers:
             y = layer(y, mem, cross_pair, self_pair)
         rows, sub = pt.tail()                                   # packed rows of positions >= 1, their [B, n-1] layout
@@ -429,10 +431,12 @@ class HiddenDecoder(nn.Module):
             pt = ops.PackedSeq(causal_lengths, x.size(1))
             y, mem = ops.pack_rows(x, pt), ops.pack_rows(memory, pm)
             self_pair, cross_pair = ops.PackedPair(pt, pt, causal=True), ops.PackedPair(pt, pm)
+            mem = ops.shared_kv(mem)
             for layer in self.layers:
                 y = layer(y, mem, cross_pair, self_pair)
             return ops.unpack_rows(y, pt)
         y = x
+        memory = ops.shared_kv(memory)      # one gradient buffer for all layers' cross-attention (ops.SharedKVFn)
         for layer in self.layers:
             y = layer(y, memory, src_mask, tgt_mask)
         return y
