@@ -127,6 +127,11 @@ def cpu_baseline(model, cfg, B, steps=5, warm=2):
 
 
 def main():
+    # stdout carries ONE JSON line: everything else that writes to file descriptor 1 (RCCL prints its version banner there under
+    # NCCL_DEBUG=VERSION, which the GPU boxes set) is sent to stderr; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -188,6 +193,7 @@ def main():
     torch.cuda.manual_seed(100 + rank)
 
     debug = os.environ.get("NAST_BENCH_DEBUG")      # rehearsal aid: progress lines + a stack dump if a step stalls
+    debug = debug if debug and int(debug) > 0 else None
     if debug:
         import faulthandler
         faulthandler.dump_traceback_later(int(debug), repeat=True, file=sys.stderr)
@@ -390,7 +396,8 @@ def main():
             out["also"] = also
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, cfg, B)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,7 +25,11 @@ the parameter group being stepped:
     leave;
   * every wait has a deadline (`NAST_DDP_TIMEOUT_S`, default 120 s): a stuck collective prints which rank waits for which
     bucket of which step variant and raises, instead of hanging until the job's time limit;
-  * parameters that never receive a gradient (sos_token, transformer.py:41; all of F during d_step) take no part.
+  * parameters that never receive a gradient (sos_token, transformer.py:41; all of F during d_step) take no part;
+  * DEFAULT since round 2: the buckets are launched from `finish()`, after backward, in layout order, from the thread and
+    stream that called it (`GradReducer.OVERLAP = False`).  Launching them from the gradient hooks while backward runs
+    (`NAST_DDP_OVERLAP=1`) saves the 62 MB all-reduce's ~1-2 ms per 45 ms step at best (one-rank rehearsal: 46.3 vs 46.6
+    ms) and was the path in use when round 1's 8-GPU run hung; with no multi-GPU box to rehearse on, the simple order wins.
 
 Local losses are divided by the LOCAL batch size (as the reference divides by its batch size); averaging
 the gradients over ranks therefore equals the single-GPU gradient on the concatenated batch when all ranks
@@ -61,6 +65,7 @@ class _Plan:
 
 class GradReducer:
     BUCKET_BYTES = 16 << 20
+    OVERLAP = os.environ.get("NAST_DDP_OVERLAP", "0") == "1"      # launch buckets from the gradient hooks during backward
 
     def __init__(self, params, bucket_bytes=None, group=None):
         bucket_bytes = self.BUCKET_BYTES if bucket_bytes is None else bucket_bytes
@@ -104,6 +109,8 @@ class GradReducer:
         if i not in plan.bucket_of:
             self._dirty = True
             return
+        if not self.OVERLAP:
+            return                              # everything leaves from finish()
         self._seen[i] = self._seen.get(i, 0) + 1
         b = plan.bucket_of[i]
         if self._launched[b]:

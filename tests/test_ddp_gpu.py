@@ -33,6 +33,10 @@ if "multibucket" in sys.argv[2]:             # several buckets in flight while b
     Seq2seq.pack_min_tokens = 0
     import nast_amd.ddp as _d
     _d.GradReducer.BUCKET_BYTES = 64 << 10
+    _d.GradReducer.OVERLAP = True            # (opt-in since round 2: the default launches the buckets after backward)
+if sys.argv[2].endswith("2streams"):
+    import nast_amd.ddp as _d
+    _d.GradReducer.OVERLAP = True
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cfg = dict(V=48, d=32, h=4, N=2, L=8, learnable=learnable, gen_approx_mode="soft", dis_approx_mode="soft")

@@ -282,13 +282,16 @@ print("ok", rank)
 '''
 
 
-def test_grad_reducer_gloo_world2(tmp_path):
-    """N-rank averaged gradients == single-process gradients on the concatenated batch."""
+@pytest.mark.parametrize("overlap,world", [("0", 2), ("1", 2), ("0", 4), ("1", 4)])
+def test_grad_reducer_gloo_world2(tmp_path, overlap, world):
+    """N-rank averaged gradients == single-process gradients on the concatenated batch, with the buckets
+    launched after backward (the default) and from the gradient hooks during backward (NAST_DDP_OVERLAP=1)."""
     script = tmp_path / "w.py"
     script.write_text(DDP_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29610 + int(overlap) + 2 * world), WORLD_SIZE=str(world),
+               OMP_NUM_THREADS="1", NAST_DDP_OVERLAP=overlap)
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
+                              stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
