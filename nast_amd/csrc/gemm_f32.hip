@@ -665,7 +665,10 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
     static const int plain_min = [] { const char* e = getenv("NAST_GEMM_PLAIN_SPLIT_MIN"); return e ? atoi(e) : 8; }();   // tuning aid
     // (a plain output is cut only from K = 2048 up: the cut costs a zero-fill and atomic stores; at K = 1024 and ~620 tiles
     // (packed rows) the uncut launch measured 70 us against 79 us)
-    can_split[i] = plain && ((D.flags & NAST_GEMM_ATOMIC) || (!(D.flags & NAST_GEMM_ACCUM) && nkt_of[i] >= plain_min * MIN_KT));
+    // (a plain output is zero-filled before its slices are added: a residual that aliases C would be erased -- such a problem
+    // is never cut)
+    const bool alias = D.residual != nullptr && D.residual == D.C;
+    can_split[i] = plain && ((D.flags & NAST_GEMM_ATOMIC) || (!alias && !(D.flags & NAST_GEMM_ACCUM) && nkt_of[i] >= plain_min * MIN_KT));
     work += (long long)P.tiles_m[i] * P.tiles_n[i] * nkt_of[i];
     if (!can_split[i] && nkt_of[i] > max_unsplit) max_unsplit = nkt_of[i];
   }

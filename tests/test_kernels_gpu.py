@@ -98,6 +98,23 @@ def test_gemm_weight_stationary(ops, M, N, transB, monkeypatch):
         relclose(y_, x.double() @ w.double().t() + b.double())
 
 
+def test_gemm_in_place_residual_with_long_k(ops):
+    """y = x W^T + b + y with the residual aliasing the output (an in-place residual update) at a K long enough for the
+    split-K plan (>= 2048): a cut output is zero-filled before its slices are added, which would erase the residual, so such a
+    problem must not be cut.  Next to it the same product with a separate residual (which IS cut)."""
+    M, N, K = 96, 64, 4096
+    g = torch.Generator().manual_seed(9)
+    x, W, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 64, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = x.double() @ W.double().t() + b.double() + r.double()
+    xd, Wd, bd = dev(x), dev(W), dev(b)
+    y = dev(r).clone()
+    ops.gemm([ops.d_fwd(xd, Wd, y, bias=bd, residual=y)])
+    relclose(y, ref)
+    y2 = torch.empty(M, N, device="cuda")
+    ops.gemm([ops.d_fwd(xd, Wd, y2, bias=bd, residual=dev(r))])
+    relclose(y2, ref)
+
+
 def test_gemm_relu_and_matmul_nn(ops):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(130, 48, generator=g)
