@@ -236,16 +236,17 @@ def main():
         dt = (time.perf_counter() - t1) / n_small
         also = {"bs64": {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_small}}
 
-        def graphed(m, data, n):
+        def graphed(m, data, n, which="f_step"):
             """the same step replayed from one HIP graph (nast_amd/graph.py): 2 eager fixed-width steps, capture, then timing"""
             m.graph_steps = True
+            step = getattr(m, which)
             try:
                 for i in range(4):
-                    m.f_step(data[i % 4], 1.0, use_inference_z=True)
+                    step(data[i % 4], 1.0, use_inference_z=True)
                 torch.cuda.synchronize()
                 t = time.perf_counter()
                 for i in range(n):
-                    m.f_step(data[i % 4], 1.0, use_inference_z=True)
+                    step(data[i % 4], 1.0, use_inference_z=True)
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t) / n
             finally:
@@ -254,6 +255,19 @@ def main():
         dtg = graphed(model, small, max(n_small, 10))
         also["bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3),
                               "note": "whole f_step replayed from one HIP graph (Seq2seq.graph_steps = True)"}
+        # the discriminator step at 64 sentences, eager and replayed, and the reference's schedule (10 d_step : 5 f_step) on both
+        for i in range(3):
+            model.d_step(small[i % 4], 1.0, use_inference_z=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_small):
+            model.d_step(small[i % 4], 1.0, use_inference_z=True)
+        torch.cuda.synchronize()
+        dtd = (time.perf_counter() - t1) / n_small
+        dtdg = graphed(model, small, max(n_small, 10), "d_step")
+        also["bs64_d_step"] = {"ms_per_step": round(dtd * 1e3, 3), "ms_per_step_graph": round(dtdg * 1e3, 3)}
+        also["bs64_schedule_blend_10d_5f"] = {"value": round(15 * 64 / (10 * dtd + 5 * dt), 2), "value_graph": round(15 * 64 / (10 * dtdg + 5 * dtg), 2),
+                                              "unit": "sentences/s"}
 
         def timed(fn, n):
             for _ in range(2):

@@ -1,4 +1,4 @@
-"""HIP-graph replay of the generator training step for small batches.
+"""HIP-graph replay of the generator and discriminator training steps for small batches.
 
 At the reference's own batch size (64 sentences, run.py:70) one f_step is ~2000 kernel launches of a few microseconds each:
 the GPU finishes them faster than Python can issue them, and the step time is the host's.  `StepGraphs` captures the whole
@@ -78,30 +78,40 @@ class StepGraphs:
             vals.append(x.detach().reshape(()).float())
         return torch.stack(vals)
 
-    def f_step(self, incoming, temperature, cyc_rec_enable, use_inference_z):
-        tr = self.tr
+    def _run(self, key, incoming, optimizer, step):
+        """step(incoming, capturing) -> tuple of 0-d tensors / None.  Eager (fixed width) for the first WARM calls of a key,
+        then captured once and replayed."""
         sent = incoming.data.sent
-        B = sent.shape[0]
-        key = ("f", B, float(temperature), bool(cyc_rec_enable), bool(use_inference_z))
-        e = self._entry(key, B, sent.device)
+        e = self._entry(key, sent.shape[0], sent.device)
         self._load(e, incoming)
-        kw = dict(use_inference_z=use_inference_z)
         if e.seen < self.WARM:
             e.seen += 1
             self.stats["eager"] += 1
             with ops.packed_rows(False), ops.fixed_width():
-                out = self._pack(tr._f_step(e.incoming, temperature, cyc_rec_enable, **kw))
+                out = self._pack(step(e.incoming, False))
             return tuple(out.tolist())
         if e.graph is None:
-            tr.optimizer_F.device_step_counter()          # created (and validated) outside the capture
+            optimizer.device_step_counter()               # created (and validated) outside the capture
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 with ops.packed_rows(False), ops.fixed_width():
-                    e.out = self._pack(tr._f_step(e.incoming, temperature, cyc_rec_enable, capturing=True, **kw))
+                    e.out = self._pack(step(e.incoming, True))
             e.graph = g
             self.stats["captured"] += 1
         e.graph.replay()
-        tr.optimizer_F.note_replayed_step()
+        optimizer.note_replayed_step()
         self.stats["replayed"] += 1
         return tuple(e.out.tolist())
+
+    def f_step(self, incoming, temperature, cyc_rec_enable, use_inference_z):
+        tr = self.tr
+        key = ("f", incoming.data.sent.shape[0], float(temperature), bool(cyc_rec_enable), bool(use_inference_z))
+        return self._run(key, incoming, tr.optimizer_F,
+                         lambda inc, cap: tr._f_step(inc, temperature, cyc_rec_enable, use_inference_z=use_inference_z, capturing=cap))
+
+    def d_step(self, incoming, temperature, use_inference_z):
+        tr = self.tr
+        key = ("d", incoming.data.sent.shape[0], float(temperature), bool(use_inference_z))
+        return self._run(key, incoming, tr.optimizer_D,
+                         lambda inc, cap: (tr._d_step(inc, temperature, use_inference_z=use_inference_z, capturing=cap),))[0]

@@ -282,10 +282,15 @@ class Seq2seq(BaseModel):
 
     def d_step(self, incoming, temperature, *, use_inference_z):
         """seq2seq.py:551-642 -> adv_loss (float)"""
+        if self.graph_steps and incoming.data.sent.is_cuda and incoming.data.sent.shape[0] * self.args.max_length < self.pack_min_tokens:
+            if self._graphs is None:
+                from .graph import StepGraphs
+                self._graphs = StepGraphs(self)
+            return self._graphs.d_step(incoming, temperature, use_inference_z)
         with ops.packed_rows(self.pack_rows and incoming.data.sent.numel() >= self.pack_min_tokens):
             out = self._d_step(incoming, temperature, use_inference_z=use_inference_z)
             ops.check_packed()
-            return out
+            return out.item()
 
     def _f_step(self, incoming, temperature, cyc_rec_enable=True, *, use_inference_z, capturing=False):
         """-> the seven results as 0-d device tensors (None where the reference reports 0); f_step reads them back.
@@ -437,7 +442,8 @@ class Seq2seq(BaseModel):
 
         return slf_rec_loss, cyc_rec_loss, adv_loss, slf_rec_length_loss, cyc_rec_length_loss, slf_gen_error, cyc_gen_error
 
-    def _d_step(self, incoming, temperature, *, use_inference_z):
+    def _d_step(self, incoming, temperature, *, use_inference_z, capturing=False):
+        """-> adv_loss as a 0-d device tensor (d_step reads it back).  capturing=True: issued under HIP-graph capture."""
         dm = self.param.volatile.dm
         self.net.model_F.eval()
         eos_idx = dm.eos_id
@@ -452,7 +458,8 @@ class Seq2seq(BaseModel):
         if ops.PACK_ROWS and inp_lengths.is_cuda:
             ops.set_total(inp_lengths, inp_lengths.sum().item())
 
-        overlap = self.overlap_passes and inp_tokens.is_cuda and inp_tokens.numel() >= self._overlap_threshold()
+        overlap = self.overlap_passes and inp_tokens.is_cuda and inp_tokens.numel() >= self._overlap_threshold() \
+            and (not capturing or self.graph_overlap)
 
         def gold_forward():
             if args.discriminator_method == 'Multi':
@@ -461,7 +468,8 @@ class Seq2seq(BaseModel):
                     torch.cat((torch.ones_like(raw_styles), torch.zeros_like(rev_styles)), 0))
 
         gold = {}
-        hook = contextlib.nullcontext()
+        # fixed-width execution: the decode runs all its steps without the early-exit read-backs
+        hook = ops.async_decode(None) if ops.FIXED_WIDTH else contextlib.nullcontext()
         if overlap:
             # The gold half of the loss needs nothing from the generator: its forward AND backward are issued on the second
             # stream from the decode hook (ops.async_decode), right behind the enqueue of the greedy decode, so they fill
@@ -503,6 +511,7 @@ class Seq2seq(BaseModel):
                     raw_gen_log_probs, rev_gen_log_probs = both_log_probs[:batch_size], both_log_probs[batch_size:]
                 if both_lengths is not None and both_packed is None:
                     raw_gen_lengths, rev_gen_lengths = both_lengths[:batch_size], both_lengths[batch_size:]
+                if both_lengths is not None and both_packed is None and not ops.FIXED_WIDTH:
                     t_raw, t_rev, s_raw, s_rev = torch.stack((raw_gen_lengths.max(), rev_gen_lengths.max(),
                                                               raw_gen_lengths.sum(), rev_gen_lengths.sum())).tolist()
                     ops.set_total(raw_gen_lengths, s_raw)
@@ -549,7 +558,8 @@ class Seq2seq(BaseModel):
             assert len(gen_log_probs.size()) == 2
             gen_part = loss_fn(gen_log_probs, gen_labels).sum() / batch_size
             main.wait_stream(side)              # the gold pass ran during the decode; the two backwards never overlap
-            gold["loss"].record_stream(main)
+            if not capturing:
+                gold["loss"].record_stream(main)
             self.reducer_D.arm("d")
             gen_part.backward()
             adv_loss = gold["loss"] + gen_part.detach()
@@ -564,6 +574,6 @@ class Seq2seq(BaseModel):
             self.reducer_D.arm("d")
             adv_loss.backward()
         self.reducer_D.finish()
-        self.last_grad_norm = self.optimizer_D.clip_and_step(5)                # seq2seq.py:637-638
+        self.last_grad_norm = self.optimizer_D.clip_and_step(5, capturing=capturing)                # seq2seq.py:637-638
         model_F.train()
-        return adv_loss.item()
+        return adv_loss

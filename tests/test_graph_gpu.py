@@ -122,3 +122,42 @@ def test_graph_replay_equals_fixed_width_eager(learnable, cyc):
     assert float(a.optimizer_F.device_step_counter().item()) == 7.0
     assert all(float(v["step"]) == 7.0 for v in a.optimizer_F.state_dict()["state"].values())
     assert r1[0] > 0
+
+
+@pytest.mark.parametrize("learnable", [True, False])
+def test_d_step_graph_replay_equals_fixed_width_eager(learnable):
+    """The discriminator step under graph_steps: two eager fixed-width steps, capture + replay, replay -- against a twin
+    trainer's eager fixed-width d_steps under the same seeds (loss per step, parameters of D, Adam state), and the
+    fixed-width eager step against the ordinary eager step where no Gumbel noise is drawn (approx mode "soft")."""
+    from nast_amd import ops
+    a = _trainer(learnable)
+    b = _trainer(learnable)
+    a.graph_steps = True
+    for step in range(4):
+        inc = _batch(20 + step, full_first=step != 2)
+        torch.manual_seed(300 + step)
+        ra = a.d_step(inc, 1.0, use_inference_z=True)
+        torch.manual_seed(300 + step)
+        incb = copy.copy(inc); incb.data = copy.copy(inc.data)
+        w = inc.data.sent.shape[1]
+        full = torch.zeros(inc.data.sent.shape[0], CFG["L"], dtype=torch.int64, device="cuda")
+        full[:, :w] = inc.data.sent
+        incb.data.sent = full
+        with ops.packed_rows(False), ops.fixed_width():
+            rb = b._d_step(incb, 1.0, use_inference_z=True).item()
+        _close((ra,), (rb,))
+    assert a._graphs.stats == {"eager": 2, "captured": 1, "replayed": 2}, a._graphs.stats
+    _same_state(a, b, 2.5e-4, mean_atol=5e-7)
+    assert all(float(v["step"]) == 4.0 for v in a.optimizer_D.state_dict()["state"].values())
+    assert float(a.optimizer_D.device_step_counter().item()) == 4.0
+    # fixed width == ordinary eager where the draws do not depend on widths
+    c = _trainer(learnable, dis_approx_mode="soft")
+    d = _trainer(learnable, dis_approx_mode="soft")
+    inc = _batch(31)
+    torch.manual_seed(5)
+    rc = c.d_step(inc, 1.0, use_inference_z=True)
+    torch.manual_seed(5)
+    with ops.packed_rows(False), ops.fixed_width(True, graph_noise=False):
+        rd = d._d_step(inc, 1.0, use_inference_z=True).item()
+    _close((rd,), (rc,))
+    _same_state(c, d, 5e-6)
