@@ -379,7 +379,7 @@ def main():
     if dist_on:
         dist.barrier()
         if debug:
-            print(f"[rank {rank}] reducer F {model.reducer_F.stats} buckets "
+            print(f"[rank {rank}] reducer F {model.reducer_F.stats} arena {model.reducer_F.arena is not None} buckets "
                   f"{ {k: [len(b) for b in p.buckets] for k, p in model.reducer_F.plans.items()} }", file=sys.stderr, flush=True)
 
     if rank == 0:

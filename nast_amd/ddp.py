@@ -64,11 +64,24 @@ class _Plan:
 
 
 class GradReducer:
-    BUCKET_BYTES = 16 << 20
+    # bucket size: 16 MiB when the buckets are to overlap backward; ONE bucket (a single all-reduce per step) in the default
+    # after-backward mode, where cutting the gradients buys nothing.  (Rehearsal on one GPU: several bucket all-reduces in
+    # flight through a gloo process group stall in gloo's device-buffer path from the second step on, with one rank as with
+    # two; one bucket runs.  RCCL with one rank runs either way.)
+    BUCKET_BYTES = int(float(os.environ["NAST_DDP_BUCKET_MB"]) * (1 << 20)) if "NAST_DDP_BUCKET_MB" in os.environ else None
+    # drain the device before the collectives of the after-backward mode are issued (the host reads the step's losses a
+    # moment later anyway): a collective then never queues behind ~40 ms of backward kernels on a shared hardware queue
+    SYNC_BEFORE = os.environ.get("NAST_DDP_SYNC", "1") == "1"
     OVERLAP = os.environ.get("NAST_DDP_OVERLAP", "0") == "1"      # launch buckets from the gradient hooks during backward
+    # After-backward mode: the .grad buffers of the group ARE slices of one flat buffer (created here, kept by
+    # zero_grad(set_to_none=False) and by the in-place gradient kernels), so the step's exchange is ONE all-reduce of that
+    # buffer and one scaling kernel -- no packing copies, no per-step plan.  Parameters that never receive a gradient hold
+    # zeros there (Adam then leaves them where they are, as it does when their .grad is None).
+    ARENA = os.environ.get("NAST_DDP_ARENA", "1") == "1"
 
     def __init__(self, params, bucket_bytes=None, group=None):
-        bucket_bytes = self.BUCKET_BYTES if bucket_bytes is None else bucket_bytes
+        if bucket_bytes is None:
+            bucket_bytes = self.BUCKET_BYTES if self.BUCKET_BYTES is not None else ((16 << 20) if self.OVERLAP else (1 << 62))
         self.params = [p for p in params if p.requires_grad]
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.group = group
@@ -82,12 +95,48 @@ class GradReducer:
         self._fired = []
         self._streams = ()
         self.stats = {"learnt": 0, "overlapped": 0, "redone": 0}     # steps by how their reduce went
+        self.arena = None
+        if self.enabled and not self.OVERLAP and self.ARENA and self.params and all(
+                p.is_cuda and p.dtype == torch.float32 and p.device == self.params[0].device for p in self.params):
+            self._make_arena()
+            self.stats = {"arena": 0}
+            return
         if self.enabled:
             from . import ops
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
             _reducers.append(self)
             ops.grad_listener = _listener
+
+    def _make_arena(self):
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += (p.numel() + 63) // 64 * 64                 # every slice starts on a 256-byte boundary
+        self.arena = torch.zeros(off, dtype=torch.float32, device=self.params[0].device)
+        self._slices = []
+        for p, o in zip(self.params, offs):
+            g = self.arena[o:o + p.numel()].view_as(p)
+            p.grad = g
+            self._slices.append(g)
+
+    def _finish_arena(self):
+        for p, g in zip(self.params, self._slices):            # (a replaced .grad would silently drop out of the exchange)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                raise RuntimeError("[nast_amd.ddp] a .grad buffer was replaced (zero_grad(set_to_none=True)?): the flat "
+                                   "gradient buffer no longer holds this group's gradients")
+        cur = torch.cuda.current_stream()
+        for st in self._streams:                                # the exchange is issued on the current stream
+            if st != cur:
+                cur.wait_stream(st)
+        if self.SYNC_BEFORE:
+            torch.cuda.synchronize()
+        self.tag = self.tag or "step"
+        self._launched = [True]
+        self._wait(dist.all_reduce(self.arena, op=dist.ReduceOp.SUM, group=self.group, async_op=True), "gradient all-reduce")
+        if self.world > 1:
+            self.arena.mul_(1.0 / self.world)
+        self.stats["arena"] += 1
 
     def _make_hook(self, i):
         def hook(_param):
@@ -126,6 +175,9 @@ class GradReducer:
         """Call right before the backward pass whose gradients are final for this step.  `streams`: every HIP
         stream that backward's kernels run on, when more than one (a bucket waits for all of them before it leaves)."""
         if not self.enabled:
+            return
+        if self.arena is not None:
+            self.tag, self._streams = tag, tuple(streams)
             return
         self.armed = True
         self.tag = tag
@@ -238,10 +290,14 @@ class GradReducer:
         """Call after that backward: waits for the buckets, writes the averaged gradients back."""
         if not self.enabled:
             return
+        if self.arena is not None:
+            return self._finish_arena()
         self.armed = False
         local_sync = self.plan is None or self._dirty
         # A rank with a plan sends ALL its buckets, in layout order, even when it already knows that it will have to redo the
         # step (its peers, which may be clean, send theirs: the sequences of collectives must be the same everywhere)
+        if self.SYNC_BEFORE and not self.OVERLAP and self.params[0].is_cuda:
+            torch.cuda.synchronize()
         if self.plan is not None:
             for b in range(len(self.plan.buckets)):
                 if not self._launched[b]:
