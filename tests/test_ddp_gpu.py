@@ -122,3 +122,75 @@ def test_two_rank_step_equals_single_process(tmp_path, mode):
     outs = [p.communicate(timeout=150)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
+
+
+RCCL_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from helpers import make_param, synth_batch
+import nast_amd.utils as U
+import nast_amd.ddp as ddp_mod
+from nast_amd.seq2seq import Seq2seq, reserve_streams
+from nast_amd.utils import Storage
+import faulthandler
+faulthandler.dump_traceback_later(100, exit=True)
+torch.cuda.set_device(0)
+reserve_streams()                                  # before RCCL takes its hardware queues (INTEGRATION.md section 1)
+ddp_mod.FORCE_SINGLE = True                        # reduce even in a group of one rank: RCCL's real launch path
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+cfg = dict(V=48, d=32, h=4, N=2, L=8, learnable=True, gen_approx_mode="soft", dis_approx_mode="soft")
+U.cuda_init(0, "cuda")
+Seq2seq.overlap_min_tokens = 0                     # both streams, as production batches
+Seq2seq.pack_min_tokens = 0
+
+
+def build():
+    torch.manual_seed(0); np.random.seed(0)
+    m = Seq2seq(make_param(device="cuda", **cfg))
+    m.net.model_F.train(); m.net.model_D.train()
+    m.net.noiseLayer.forward = lambda w, l, rev_domain: (w, l)
+    return m
+
+
+dp = build()
+assert dp.reducer_F.enabled and dp.reducer_F.arena is not None and dp.reducer_D.arena is not None
+ddp_mod.ENABLED = False
+ref = build()
+ddp_mod.ENABLED = True
+assert not ref.reducer_F.enabled
+rng = np.random.default_rng(3)
+for step in range(3):
+    sent, slen = synth_batch(rng, 8, cfg["L"], cfg["V"])
+    inc = Storage(); inc.data = Storage()
+    inc.data.sent, inc.data.sent_length, inc.data.domain = sent.cuda(), slen.cuda(), torch.tensor([0, 0, 1, 1] * 2).cuda()
+    fn = "f_step" if step < 2 else "d_step"
+    a = getattr(dp, fn)(inc, 1.0, use_inference_z=True)
+    b = getattr(ref, fn)(inc, 1.0, use_inference_z=True)
+    assert np.allclose(np.asarray(a, dtype=float), np.asarray(b, dtype=float), rtol=1e-5, atol=1e-6), (step, a, b)
+    group = "model_F." if step < 2 else "model_D."
+    pairs = [(n, p.grad, q.grad) for (n, p), (_, q) in zip(dp.net.named_parameters(), ref.net.named_parameters())
+             if n.startswith(group) and q.grad is not None]
+    assert len(pairs) > 20
+    scale = max(q.abs().max().item() for _, _, q in pairs)
+    worst = max((g - q).abs().max().item() for _, g, q in pairs) / scale
+    assert worst < 1e-5, (step, worst)
+    # every gradient of the group is a slice of the flat buffer that went through the all-reduce
+    lo, hi = dp.reducer_F.arena.data_ptr(), dp.reducer_F.arena.data_ptr() + dp.reducer_F.arena.numel() * 4
+    assert all(lo <= p.grad.data_ptr() < hi for p in dp.reducer_F.params)
+assert dp.reducer_F.stats == {"arena": 2} and dp.reducer_D.stats == {"arena": 1}, (dp.reducer_F.stats, dp.reducer_D.stats)
+dist.destroy_process_group()
+print("ok")
+'''
+
+
+def test_one_rank_rccl_group_step_equals_plain_step(tmp_path):
+    """The default exchange (gradients in one flat buffer, one all-reduce after backward) through a real RCCL process group --
+    of one rank, which is what a one-GPU box can hold: f_step, f_step, d_step give the losses and gradients of a trainer that
+    takes no part in the group."""
+    script = tmp_path / "w.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", NAST_DDP_TIMEOUT_S="40", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=170)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
