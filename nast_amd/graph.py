@@ -31,6 +31,7 @@ class _Entry:
 
 class StepGraphs:
     WARM = 2
+    MAX_KEYS = 16        # a temperature schedule that changes every step never repeats a key: such keys stay eager and are dropped
 
     def __init__(self, trainer):
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
@@ -52,6 +53,13 @@ class StepGraphs:
             e.incoming.data = Storage()
             e.incoming.data.sent, e.incoming.data.sent_length, e.incoming.data.domain = e.sent, e.length, e.domain
             e.incoming.data.batch_size, e.incoming.data.seqlen = B, L
+            if len(self.entries) >= self.MAX_KEYS:                  # forget the oldest key that never reached a capture
+                for k, old in self.entries.items():
+                    if old.graph is None:
+                        del self.entries[k]
+                        break
+                else:
+                    raise RuntimeError(f"graph_steps: more than {self.MAX_KEYS} captured step variants alive")
             self.entries[key] = e
         return e
 
