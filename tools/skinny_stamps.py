@@ -1,9 +1,14 @@
+"""Reader for the in-kernel phase stamps of the small-M GEMM (round-2 study).  Needs a STAMPED build of
+gemm_f32.hip (clock64() stamps accumulated into a __device__ array by workgroup 0 and an exported nast_skinny_dbg(); the
+patch is not part of the product kernel): on the shipped library this script says so and exits."""
 import ctypes as C, os, sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import torch
 from helpers import make_param
 from nast_amd import ops, transformer as tf, _lib
 lib = C.CDLL(os.path.join("nast_amd", "lib", "libnast_hip.so"))
+if not hasattr(lib, "nast_skinny_dbg"):
+    sys.exit("this libnast_hip.so carries no stamps (see the docstring)")
 torch.manual_seed(0)
 F = tf.StyleTransformer(make_param(V=9600, d=256, h=4, N=4, L=32, learnable=True)).cuda()
 lp = F.length_predictor
