@@ -120,7 +120,10 @@ int nast_mha_fwd_varlen_f32(const float* q, const float* k, const float* v, floa
                             int q_total, int q_alloc, int k_total, int k_alloc /* rows [total, alloc) of the outputs are
                             buffer padding: written as zeros (alloc == total: none) */,
                             float scale, void* stream);
-int nast_mha_bwd_varlen_f32(const float* q, const float* k, const float* v, const float* dout, const float* lse,
+int nast_mha_bwd_varlen_f32(const float* q, const float* k, const float* v,
+                            const float* out /* the forward result (row pitch ldo) or NULL; given it, delta = rowsum(dO * O)
+                            is read off the rows and dQ and dK / dV are computed side by side (<= 64 positions) */,
+                            const float* dout, const float* lse,
                             float* dq, float* dk, float* dv, int B, int h, int max_nq, int max_nk, int dk_head,
                             int ldq, int ldk, int ldv, int ldo,
                             const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len,

@@ -57,7 +57,7 @@ SIGNATURES = {
     "nast_mha_fwd_f32": [c_fp] * 6 + [_i] * 9 + [_i64] * 6 + [_f, c_fp],
     "nast_mha_bwd_f32": [c_fp] * 10 + [_i] * 9 + [_i64] * 6 + [_f, c_fp],
     "nast_mha_fwd_varlen_f32": [c_fp] * 5 + [_i] * 9 + [c_fp] * 4 + [_i] * 5 + [_f, c_fp],
-    "nast_mha_bwd_varlen_f32": [c_fp] * 8 + [_i] * 9 + [c_fp] * 4 + [_i] * 5 + [_f, c_fp],
+    "nast_mha_bwd_varlen_f32": [c_fp] * 9 + [_i] * 9 + [c_fp] * 4 + [_i] * 5 + [_f, c_fp],
     "nast_log_softmax_fwd_f32": [c_fp, Rows, c_fp, Rows, _i, _i, _f, c_fp],
     "nast_log_softmax_bwd_f32": [c_fp, Rows, c_fp, Rows, c_fp, Rows, _i, _i, _f, c_fp],
     "nast_gumbel_softmax_fwd_f32": [c_fp, Rows, c_fp, Rows, c_fp, c_fp, Rows, c_fp, _i, _i, _f, _u64, _u64, _i, c_fp],

@@ -234,8 +234,8 @@ int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint
                       int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s, const int32_t* q_off = nullptr,
                       const int32_t* k_off = nullptr, const int32_t* q_len = nullptr, const int32_t* k_len = nullptr, int causal = 0,
                       int q_total = 0, int q_alloc = 0, int k_total = 0, int k_alloc = 0);
-int nast_mha_bwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, const float* dout, const float* lse, float* dq,
-                      float* dk_, float* dv, int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs,
+int nast_mha_bwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, const float* out, const float* dout,
+                      const float* lse, float* dq, float* dk_, float* dv, int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs,
                       int64_t k_bs, int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s,
                       const int32_t* q_off = nullptr, const int32_t* k_off = nullptr, const int32_t* q_len = nullptr,
                       const int32_t* k_len = nullptr, int causal = 0, int q_total = 0, int q_alloc = 0, int k_total = 0, int k_alloc = 0);
@@ -309,14 +309,13 @@ extern "C" int nast_mha_bwd_f32(const float* q, const float* k, const float* v, 
                                 const float* dout, const float* lse, float* dq, float* dk_, float* dv, int B, int h, int nq,
                                 int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs, int64_t k_bs, int64_t v_bs,
                                 int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, void* stream) {
-  (void)out;
   int rc = check_common("nast_mha_bwd_f32", B, h, nq, nk, dk, ldq, ldk, ldv, ldo);
   if (rc) return rc;
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(q && k && v && dout && lse && dq && dk_ && dv, "nast_mha_bwd_f32: NULL pointer");
   hipStream_t s = (hipStream_t)stream;
   if (((q_bs | k_bs | v_bs | o_bs) & 3) == 0 &&
-      nast_mha_bwd_mfma(q, k, v, mask, dout, lse, dq, dk_, dv, B, h, nq, nk, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s) == 0) {
+      nast_mha_bwd_mfma(q, k, v, mask, out, dout, lse, dq, dk_, dv, B, h, nq, nk, dk, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, mask_bs, mask_qs, scale, s) == 0) {
     NAST_CHECK_LAUNCH("nast_mha_bwd_f32(mfma)");
     return NAST_OK;
   }
@@ -350,8 +349,8 @@ extern "C" int nast_mha_fwd_varlen_f32(const float* q, const float* k, const flo
   return NAST_OK;
 }
 
-extern "C" int nast_mha_bwd_varlen_f32(const float* q, const float* k, const float* v, const float* dout, const float* lse, float* dq,
-                                       float* dk_, float* dv, int B, int h, int max_nq, int max_nk, int dk, int ldq, int ldk, int ldv,
+extern "C" int nast_mha_bwd_varlen_f32(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                       const float* lse, float* dq, float* dk_, float* dv, int B, int h, int max_nq, int max_nk, int dk, int ldq, int ldk, int ldv,
                                        int ldo, const int32_t* q_off, const int32_t* k_off, const int32_t* q_len,
                                        const int32_t* k_len, int causal, int q_total, int q_alloc, int k_total, int k_alloc,
                                        float scale, void* stream) {
@@ -362,7 +361,7 @@ extern "C" int nast_mha_bwd_varlen_f32(const float* q, const float* k, const flo
   NAST_REQUIRE(max_nq <= 144 && max_nk <= 144, "nast_mha_bwd_varlen_f32: lengths up to 144 (got %d, %d)", max_nq, max_nk);
   NAST_REQUIRE(q_total >= 0 && q_alloc >= q_total && k_total >= 0 && k_alloc >= k_total, "nast_mha_bwd_varlen_f32: row counts");
   NAST_REQUIRE(((ldq | ldk | ldv | ldo) & 3) == 0, "nast_mha_bwd_varlen_f32: row pitches must be multiples of 4");
-  rc = nast_mha_bwd_mfma(q, k, v, nullptr, dout, lse, dq, dk_, dv, B, h, max_nq, max_nk, dk, ldq, ldk, ldv, ldo, 0, 0, 0, 0, 0, 0, scale,
+  rc = nast_mha_bwd_mfma(q, k, v, nullptr, out, dout, lse, dq, dk_, dv, B, h, max_nq, max_nk, dk, ldq, ldk, ldv, ldo, 0, 0, 0, 0, 0, 0, scale,
                          (hipStream_t)stream, q_off, k_off, q_len, k_len, causal, q_total, q_alloc, k_total, k_alloc);
   NAST_REQUIRE(rc == 0, "nast_mha_bwd_varlen_f32: head size %d not supported at these lengths (8 needs <= 64 positions)", dk);
   NAST_CHECK_LAUNCH("nast_mha_bwd_varlen_f32");

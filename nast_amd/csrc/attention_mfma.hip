@@ -25,6 +25,16 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef ATTN_STAMPS   // debug build only (tools/attn_stamps.py): per-workgroup s_memtime stamps of the backward kernel's segments
+__device__ unsigned long long g_attn_stamps[8192 * 8];
+#define ATTN_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_attn_stamps[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int nast_attn_stamps_read(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * n);
+}
+#else
+#define ATTN_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 template <int DK>
@@ -60,7 +70,7 @@ __device__ __forceinline__ float xor_sum_15(float v) {  // over the 16 lanes of 
 }
 
 struct AttnArgs {
-  const float *q, *k, *v, *dout, *lse_in;
+  const float *q, *k, *v, *dout, *lse_in, *o_in;   // o_in: forward output for the backward pass, or NULL
   const uint8_t* mask;
   float *out, *lse, *dq, *dk, *dv;
   int BH, h, nq, nk, ldq, ldk, ldv, ldo;
@@ -244,7 +254,14 @@ __device__ __forceinline__ void stage_rows_flag(float* __restrict__ dst, const f
   }
 }
 
-template <int DK, int NT>
+// SPLIT (the caller passed the forward output O): delta[i] = sum_j P[i][j] dP[i][j] = sum_c dO[i][c] O[i][c] is then taken
+// from the rows while they are staged, so phase 2 no longer waits for phase 1: there is no barrier between them and the
+// 16-row tiles of both are dealt to the four wavefronts together (sentences of up to 32 positions: two wavefronts on dQ, two
+// on dK / dV at the same time, where the two-phase form leaves two of the four idle in each phase).
+// (Tried on top of SPLIT and dropped, round 2: a streaming form -- 2 workgroups per CU walking the items with the NEXT item's
+// rows requested into registers before the current item's arithmetic -- needs > 256 VGPRs (11-52 spilled) and with 8 wavefronts
+// per CU runs 35.6 / 62.8 us where this form takes 30.9 / 41.8 at 32 / 34 positions, 512 sentences x 4 heads.)
+template <int DK, int NT, bool SPLIT>
 __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel(const AttnArgs P) {
   constexpr int NS = DK / 4, NCT = (DK + 15) / 16, LD = DK + 4;
   __shared__ __attribute__((aligned(16))) float Ks[NT * 16 * LD];
@@ -256,7 +273,85 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
   __shared__ unsigned long long dead_q[NT * 16];   // per query: bit j set = key j gets no attention weight
   __shared__ unsigned long long dead_k[NT * 16];   // per key: bit i set = query i gives it no weight
   __shared__ int live_q[NT];                    // query tile has a non-zero dO row
+  static_assert(NT * 16 <= 256, "one log-sum-exp value per thread");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r15 = lane & 15, g = lane >> 4;
+  const float scale = P.scale;
+  const bool pad_mask = P.mask != nullptr && P.mask_qs == 0;
+  constexpr int V4 = DK / 4, CH = (NT * 16 * V4 + 255) / 256;
+  // everything the kernel reads, held in registers from `fetch` to `commit`: K, V, Q, dO (and O) rows, the log-sum-exp row,
+  // mask bytes for the dead flags of both orientations -- ONE memory round trip
+  float4 rk[CH], rv[CH], rq[CH], rg[CH], ro[SPLIT ? CH : 1];
+  uint8_t mq_b[NT * 4], mk_b[NT * 4];
+  float lse_r = 0.f;
+  auto fetch = [&](int bh, const SeqGeom& G) {
+    const int b = bh / P.h, head = bh % P.h, nq = G.nq, nk = G.nk;
+    if (nq <= 0 || nk <= 0) return;             // (uniform for the workgroup)
+    // mask bytes: NT*4 rows of each orientation per wavefront (lane = key for dead_q, lane = query for dead_k)
+#pragma unroll
+    for (int u = 0; u < NT * 4; ++u) {
+      const int row = 4 * u + wave;
+      const int ic = row < nq ? row : nq - 1, jl = lane < nk ? lane : nk - 1;
+      const int jc = row < nk ? row : nk - 1, il = lane < nq ? lane : nq - 1;
+      mq_b[u] = P.mask != nullptr ? P.mask[b * P.mask_bs + (int64_t)ic * P.mask_qs + jl] : (uint8_t)0;
+      mk_b[u] = P.mask != nullptr ? P.mask[b * P.mask_bs + (int64_t)il * P.mask_qs + jc] : (uint8_t)0;
+    }
+    const int nqt = (nq + 15) / 16;
+    lse_r = (int)threadIdx.x < nqt * 16 ? P.lse_in[(int64_t)bh * P.nq + ((int)threadIdx.x < nq ? (int)threadIdx.x : nq - 1)] : 0.f;
+    const float* Kg = P.k + G.k0 + head * DK;
+    const float* Vg = P.v + G.v0 + head * DK;
+    const float* Qg = P.q + G.q0 + head * DK;
+    const float* Gg = P.dout + G.o0 + head * DK;
+    const float* Og = SPLIT ? P.o_in + G.o0 + head * DK : nullptr;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int c = threadIdx.x + 256 * u, r = c / V4, q = (c % V4) * 4;
+      rk[u] = rv[u] = rq[u] = rg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (SPLIT) ro[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nk) {
+        rk[u] = *reinterpret_cast<const float4*>(Kg + (int64_t)r * P.ldk + q);
+        rv[u] = *reinterpret_cast<const float4*>(Vg + (int64_t)r * P.ldv + q);
+      }
+      if (r < nq) {
+        rq[u] = *reinterpret_cast<const float4*>(Qg + (int64_t)r * P.ldq + q);
+        rg[u] = *reinterpret_cast<const float4*>(Gg + (int64_t)r * P.ldo + q);
+        if constexpr (SPLIT) ro[u] = *reinterpret_cast<const float4*>(Og + (int64_t)r * P.ldo + q);
+      }
+    }
+  };
+  // registers -> LDS images (rows past the sequence end zero-filled), delta, log-sum-exp, dead-flag bit rows by wave ballots
+  auto commit = [&](const SeqGeom& G) {
+    const int nq = G.nq, nk = G.nk, nqt = (nq + 15) / 16;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int c = threadIdx.x + 256 * u, r = c / V4, q = (c % V4) * 4;
+      if (r < NT * 16) {
+        *reinterpret_cast<float4*>(Ks + r * LD + q) = rk[u];
+        *reinterpret_cast<float4*>(Vs + r * LD + q) = rv[u];
+        *reinterpret_cast<float4*>(Qs + r * LD + q) = rq[u];
+        *reinterpret_cast<float4*>(Gs + r * LD + q) = rg[u];
+        if (rg[u].x != 0.f || rg[u].y != 0.f || rg[u].z != 0.f || rg[u].w != 0.f) live_q[r >> 4] = 1;   // benign race: all store 1
+      }
+      if constexpr (SPLIT) {                     // delta of row r: the V4 consecutive lanes that hold the row add their pieces
+        float part = rg[u].x * ro[u].x + rg[u].y * ro[u].y + rg[u].z * ro[u].z + rg[u].w * ro[u].w;
+#pragma unroll
+        for (int o = V4 / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (c % V4 == 0 && r < NT * 16) dlt[r] = part;
+      }
+    }
+    if ((int)threadIdx.x < nqt * 16) lse_s[threadIdx.x] = lse_r;
+#pragma unroll
+    for (int u = 0; u < NT * 4; ++u) {
+      const int row = 4 * u + wave;
+      const unsigned long long mq = __ballot(row >= nq || lane >= nk || mq_b[u] != 0 || (P.causal && lane > row));
+      const unsigned long long mk = __ballot(row >= nk || lane >= nq || mk_b[u] != 0 || (P.causal && row > lane));
+      if (lane == 0) {
+        dead_q[row] = mq;
+        dead_k[row] = mk;
+      }
+    }
+  };
+
+  ATTN_STAMP(0);
   const int bh = blockIdx.x;
   const int b = bh / P.h, head = bh % P.h;
   const SeqGeom G = seq_geom(P, b);
@@ -270,70 +365,15 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
   float* dQb = P.dq + G.q0 + head * DK;
   float* dKb = P.dk + G.k0 + head * DK;
   float* dVb = P.dv + G.v0 + head * DK;
-  const float scale = P.scale;
   const int nqt = (nq + 15) / 16, nkt = (nk + 15) / 16;
-  // Everything the two phases read comes to LDS in ONE global round trip: K, V, Q, dO rows, the log-sum-exp row and
-  // the mask as dead flags in both orientations.  Keys past the last unmasked one (same for every query when
-  // mask_qs == 0) never take part.
-  const bool pad_mask = P.mask != nullptr && P.mask_qs == 0;
   if (threadIdx.x < NT) live_q[threadIdx.x] = 0;
+  __syncthreads();                              // (before the loads are requested: a barrier waits for everything in flight)
+  fetch(bh, G);
+  ATTN_STAMP(1);
+  commit(G);
+  ATTN_STAMP(2);
   __syncthreads();
-  // mask bytes: NT*4 rows of each orientation per wavefront (lane = key for dead_q, lane = query for dead_k)
-  uint8_t mq_b[NT * 4], mk_b[NT * 4];
-#pragma unroll
-  for (int u = 0; u < NT * 4; ++u) {
-    const int row = 4 * u + wave;
-    const int ic = row < nq ? row : nq - 1, jl = lane < nk ? lane : nk - 1;
-    const int jc = row < nk ? row : nk - 1, il = lane < nq ? lane : nq - 1;
-    mq_b[u] = P.mask != nullptr ? P.mask[b * P.mask_bs + (int64_t)ic * P.mask_qs + jl] : (uint8_t)0;
-    mk_b[u] = P.mask != nullptr ? P.mask[b * P.mask_bs + (int64_t)il * P.mask_qs + jc] : (uint8_t)0;
-  }
-  {
-    // all global loads of the four operand images are issued before the first LDS store (one memory round trip)
-    constexpr int V4 = DK / 4, CH = (NT * 16 * V4 + 255) / 256;
-    float4 rk[CH], rv[CH], rq[CH], rg[CH];
-    const float* Kg = P.k + G.k0 + head * DK;
-    const float* Vg = P.v + G.v0 + head * DK;
-    const float* Qg = P.q + G.q0 + head * DK;
-    const float* Gg = P.dout + G.o0 + head * DK;
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const int c = threadIdx.x + 256 * u, r = c / V4, q = (c % V4) * 4;
-      rk[u] = rv[u] = rq[u] = rg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < nk) {
-        rk[u] = *reinterpret_cast<const float4*>(Kg + (int64_t)r * P.ldk + q);
-        rv[u] = *reinterpret_cast<const float4*>(Vg + (int64_t)r * P.ldv + q);
-      }
-      if (r < nq) {
-        rq[u] = *reinterpret_cast<const float4*>(Qg + (int64_t)r * P.ldq + q);
-        rg[u] = *reinterpret_cast<const float4*>(Gg + (int64_t)r * P.ldo + q);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      const int c = threadIdx.x + 256 * u, r = c / V4, q = (c % V4) * 4;
-      if (r < NT * 16) {
-        *reinterpret_cast<float4*>(Ks + r * LD + q) = rk[u];
-        *reinterpret_cast<float4*>(Vs + r * LD + q) = rv[u];
-        *reinterpret_cast<float4*>(Qs + r * LD + q) = rq[u];
-        *reinterpret_cast<float4*>(Gs + r * LD + q) = rg[u];
-        if (rg[u].x != 0.f || rg[u].y != 0.f || rg[u].z != 0.f || rg[u].w != 0.f) live_q[r >> 4] = 1;   // benign race: all store 1
-      }
-    }
-  }
-  for (int i = threadIdx.x; i < nqt * 16; i += 256) lse_s[i] = P.lse_in[(int64_t)bh * P.nq + (i < nq ? i : nq - 1)];
-  // dead-flag bit rows by wave ballots (the bytes were requested before the operand images)
-#pragma unroll
-  for (int u = 0; u < NT * 4; ++u) {
-    const int row = 4 * u + wave;
-    const unsigned long long mq = __ballot(row >= nq || lane >= nk || mq_b[u] != 0 || (P.causal && lane > row));
-    const unsigned long long mk = __ballot(row >= nk || lane >= nq || mk_b[u] != 0 || (P.causal && row > lane));
-    if (lane == 0) {
-      dead_q[row] = mq;
-      dead_k[row] = mk;
-    }
-  }
-  __syncthreads();
+  ATTN_STAMP(3);
   // keys past the last one that any query may see never take part (a key-padding mask hides the sentence tail)
   int nk_e = nk;
   if (pad_mask) {
@@ -343,13 +383,13 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
   const int nkt_e = (nk_e + 15) / 16;
 
   // ---- phase 1: lane = query.  dQ[i][c] = scale * sum_j dS[i][j] K[j][c] -----------------------------------
-  for (int it = wave; it < nqt; it += 4) {
+  auto phase1_tile = [&](int it) {
     if (!live_q[it]) {                           // dO == 0 for the whole tile: dQ rows are zero
       for (int c = lane; c < 16 * (DK / 4); c += 64) {
         const int io = 16 * it + c / (DK / 4), q4 = (c % (DK / 4)) * 4;
         if (io < nq) *reinterpret_cast<float4*>(dQb + (int64_t)io * P.ldq + q4) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      continue;
+      return;
     }
     // the tile's work for NKE live key tiles; NKE is a compile-time constant so that every loop unrolls and the
     // score registers stay registers
@@ -385,8 +425,12 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
           dsum = fmaf(p, dp[jt][r], dsum);
         }
       }
-      dsum = xor_sum_g(dsum);
-      if (g == 0) dlt[16 * it + r15] = dsum;
+      if (SPLIT) {
+        dsum = dlt[16 * it + r15];
+      } else {
+        dsum = xor_sum_g(dsum);
+        if (g == 0) dlt[16 * it + r15] = dsum;
+      }
 #pragma unroll
       for (int jt = 0; jt < NKE; ++jt)
 #pragma unroll
@@ -422,11 +466,10 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
     else if (NT >= 3 && nkt_e == 3) q_tile(std::integral_constant<int, NT >= 3 ? 3 : 1>{});
     else if (NT >= 2 && nkt_e == 2) q_tile(std::integral_constant<int, NT >= 2 ? 2 : 1>{});
     else q_tile(std::integral_constant<int, 1>{});
-  }
-  __syncthreads();   // dlt is read by other wavefronts below
+  };
 
   // ---- phase 2: lane = key.  dK[j][c] = scale * sum_i dS[i][j] Q[i][c],  dV[j][c] = sum_i P[i][j] dO[i][c] ----
-  for (int jt = wave; jt < nkt; jt += 4) {
+  auto phase2_tile = [&](int jt) {
     if (jt >= nkt_e) {                            // every key of the tile is masked: dK = dV = 0
       for (int c = lane; c < 16 * (DK / 4); c += 64) {
         const int jo = 16 * jt + c / (DK / 4), q4 = (c % (DK / 4)) * 4;
@@ -435,7 +478,7 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
           *reinterpret_cast<float4*>(dVb + (int64_t)jo * P.ldv + q4) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-      continue;
+      return;
     }
     float kf[NS], vf[NS];                        // this lane's key: j = 16 jt + r15
     lds_frag<DK>(kf, Ks + (16 * jt + r15) * LD, g);
@@ -502,7 +545,24 @@ __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel
         }
       }
     }
+  };
+  if (SPLIT) {
+    // task t: bit 1 = phase, tile = 2 (t >> 2) + (t & 1); wavefront w takes t = w, w + 4: up to two tiles per side run at once
+    for (int t = wave; t < 4 * ((NT + 1) / 2); t += 4) {
+      const int tile = 2 * (t >> 2) + (t & 1);
+      if ((t >> 1) & 1) {
+        if (tile < nkt) phase2_tile(tile);
+      } else if (tile < nqt) {
+        phase1_tile(tile);
+      }
+    }
+  } else {
+    for (int it = wave; it < nqt; it += 4) phase1_tile(it);
+    __syncthreads();   // dlt is read by other wavefronts below
+    ATTN_STAMP(4);
+    for (int jt = wave; jt < nkt; jt += 4) phase2_tile(jt);
   }
+  ATTN_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1041,11 +1101,22 @@ int launch_fwd_nt(const AttnArgs& A, int nkt, hipStream_t s) {
 template <int DK>
 int launch_bwd_nt(const AttnArgs& A, int nt, hipStream_t s) {
   const dim3 grid(A.BH), block(256);
+  static const bool split_ok = [] { const char* e = getenv("NAST_ATTN_SPLIT"); return !e || atoi(e) != 0; }();   // A/B aid
+  // (measured, 4 heads of 64: split wins 10-16 % from ~1000 items on; on a few hundred items, or at 49-64 positions where a
+  // wavefront carries two tiles per side either way, the extra read of O makes it 1-7 % slower)
+  if (A.o_in != nullptr && split_ok && nt <= 3 && A.BH >= 1024) {
+    switch (nt) {
+      case 1: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 1, true>), grid, block, 0, s, A); break;
+      case 2: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 2, true>), grid, block, 0, s, A); break;
+      default: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 3, true>), grid, block, 0, s, A); break;
+    }
+    return 0;
+  }
   switch (nt) {
-    case 1: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 1>), grid, block, 0, s, A); break;
-    case 2: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 2>), grid, block, 0, s, A); break;
-    case 3: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 3>), grid, block, 0, s, A); break;
-    default: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 4>), grid, block, 0, s, A); break;
+    case 1: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 1, false>), grid, block, 0, s, A); break;
+    case 2: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 2, false>), grid, block, 0, s, A); break;
+    case 3: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 3, false>), grid, block, 0, s, A); break;
+    default: hipLaunchKernelGGL((nast_mha_bwd_mfma_kernel<DK, 4, false>), grid, block, 0, s, A); break;
   }
   return 0;
 }
@@ -1074,14 +1145,14 @@ int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint
   return 1;
 }
 
-int nast_mha_bwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, const float* dout, const float* lse, float* dq,
-                      float* dk_, float* dv, int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs,
+int nast_mha_bwd_mfma(const float* q, const float* k, const float* v, const uint8_t* mask, const float* out, const float* dout,
+                      const float* lse, float* dq, float* dk_, float* dv, int B, int h, int nq, int nk, int dk, int ldq, int ldk, int ldv, int ldo, int64_t q_bs,
                       int64_t k_bs, int64_t v_bs, int64_t o_bs, int64_t mask_bs, int64_t mask_qs, float scale, hipStream_t s,
                       const int32_t* q_off, const int32_t* k_off, const int32_t* q_len, const int32_t* k_len, int causal, int q_total, int q_alloc, int k_total, int k_alloc) {
   AttnArgs A = {};
   A.q_off = q_off; A.k_off = k_off; A.q_len = q_len; A.k_len = k_len; A.causal = causal;
   A.q_total = q_total; A.q_alloc = q_alloc; A.k_total = k_total; A.k_alloc = k_alloc;
-  A.q = q; A.k = k; A.v = v; A.mask = mask; A.dout = dout; A.lse_in = lse; A.dq = dq; A.dk = dk_; A.dv = dv;
+  A.q = q; A.k = k; A.v = v; A.mask = mask; A.dout = dout; A.o_in = out; A.lse_in = lse; A.dq = dq; A.dk = dk_; A.dv = dv;
   A.BH = B * h; A.h = h; A.nq = nq; A.nk = nk; A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.ldo = ldo;
   A.q_bs = q_bs; A.k_bs = k_bs; A.v_bs = v_bs; A.o_bs = o_bs; A.mask_bs = mask_bs; A.mask_qs = mask_qs; A.scale = scale;
   if (nq > 64 || nk > 64) return dispatch_long(A, dk, true, s);

@@ -864,7 +864,11 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
     // every d_model-sized problem of the step (finer quantisation over 256 CUs, prologue/epilogue of one
     // workgroup hidden behind three others); 128x128 only wins (3-8 %) once there are thousands of tiles
     static const int t128_min = [] { const char* e = getenv("NAST_GEMM_T128_MIN"); return e ? atoi(e) : 4096; }();   // tuning aid
-    int cfg = tilesL >= t128_min ? 2 : 0;
+    // the bf16 variant's inner loop is ~3x shorter, so its time is operand traffic: the larger tile (half the re-reads)
+    // wins from ~128 tiles on (32.8-33.7 against 33.6-34.5 ms per step at 512 sentences; run-to-run spread 0.5 ms)
+    bool all_bf16 = true;
+    for (int i = 0; i < nrest; ++i) all_bf16 = all_bf16 && (rest[i].flags & NAST_GEMM_BF16);
+    int cfg = tilesL >= (all_bf16 ? std::min(t128_min, 128) : t128_min) ? 2 : 0;
     if (force >= 0) cfg = force;
     if (cfg == 2) plan_and_launch<128, 128, NAST_BK128>(rest, nrest, stream, false, nullptr);
     else plan_and_launch<64, 64, 32>(rest, nrest, stream, false, nullptr);

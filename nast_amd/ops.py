@@ -666,11 +666,13 @@ def mha_fwd_packed(q, k, v, pair, h):
     return out, lse                                # (padding rows, which belong to no sentence, come back as zeros)
 
 
-def mha_bwd_packed(q, k, v, pair, h, dout, lse):
+def mha_bwd_packed(q, k, v, pair, h, dout, lse, out=None):
+    """out: the forward result [Rq, D] when the caller still has it (the kernel then takes delta from dO * O and runs
+    its dQ and dK / dV halves side by side)."""
     D = q.shape[1]
     dk = D // h
     dq, dk_, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    call("nast_mha_bwd_varlen_f32", _p(q), _p(k), _p(v), _p(dout), _p(lse), _p(dq), _p(dk_), _p(dv), pair.q.B, h, pair.q.width,
+    call("nast_mha_bwd_varlen_f32", _p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), _p(dq), _p(dk_), _p(dv), pair.q.B, h, pair.q.width,
          pair.k.width, dk, D, D, D, D, _p(pair.q.off32), _p(pair.k.off32), _p(pair.q.len32), _p(pair.k.len32),
          int(pair.causal), pair.q.total, q.shape[0], pair.k.total, k.shape[0], 1.0 / math.sqrt(dk), _stream())
     return dq, dk_, dv                             # (padding rows get exactly zero gradient, written by the kernel)
@@ -788,7 +790,7 @@ class AttnSublayerFn(torch.autograd.Function):
         da = torch.empty_like(a).view(-1, d)
         gemm([d_dgrad([dy2], [Wo], da)] + wgrad_descs(dy2, a.view(-1, d), dWo, dbo))
         if ctx.packed:
-            dq, dk_, dv = mha_bwd_packed(q, k, v, ctx.mask, ctx.h, da, lse)
+            dq, dk_, dv = mha_bwd_packed(q, k, v, ctx.mask, ctx.h, da, lse, a.view(-1, d))
         else:
             B, nq = ctx.xshape[0], ctx.xshape[1]
             nk = nq if ctx.self_attn else ctx.kvshape[1]

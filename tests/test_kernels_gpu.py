@@ -188,7 +188,9 @@ def ref_attention(q, k, v, mask, h):
                                                 # 65 .. 144 positions: the *_long kernels (K/V resident, Q/dO in blocks of 64 queries)
                                                 (3, 129, 129, 2, 64, "pad"), (2, 100, 130, 2, 32, "pad"), (2, 80, 80, 2, 16, "causal"),
                                                 (2, 144, 144, 1, 64, "none"), (2, 65, 129, 2, 64, "causal"), (2, 130, 40, 2, 64, "pad"),
-                                                (2, 150, 150, 1, 64, "pad")])
+                                                (2, 150, 150, 1, 64, "pad"),
+                                                # >= 1024 (sentence, head) items: the backward's split form (delta from dO * O)
+                                                (260, 33, 33, 4, 64, "pad"), (300, 20, 30, 4, 32, "causal"), (520, 12, 16, 2, 16, "pad")])
 def test_attention(ops, B, nq, nk, h, dk, kind):
     g = torch.Generator().manual_seed(B * 100 + nq)
     D = h * dk
@@ -212,7 +214,8 @@ def test_attention(ops, B, nq, nk, h, dk, kind):
 
 
 @pytest.mark.parametrize("B,n,h,dk,holes", [(6, 33, 4, 64, False), (5, 48, 2, 32, False), (4, 33, 4, 64, True), (3, 20, 4, 16, True),
-                                            (5, 129, 2, 64, False), (4, 100, 2, 32, True), (3, 144, 1, 16, True)])
+                                            (5, 129, 2, 64, False), (4, 100, 2, 32, True), (3, 144, 1, 16, True),
+                                            (280, 33, 4, 64, True), (300, 40, 4, 32, False)])    # (>= 1024 items: split form)
 def test_attention_ragged_backward(ops, B, n, h, dk, holes):
     """The backward kernel skips key tiles masked for every query and query tiles whose cotangent rows are all zero
     (what a ragged batch looks like: padded positions carry no loss).  Both short cuts must be exact, also for a key
@@ -523,7 +526,9 @@ def test_fused_adam_matches_torch(ops, max_norm, wd):
 
 
 @pytest.mark.parametrize("B,nq,nk,h,dk", [(6, 33, 33, 4, 64), (5, 20, 48, 2, 32), (3, 64, 17, 4, 16), (4, 9, 9, 2, 8),
-                                          (5, 129, 129, 2, 64), (4, 70, 130, 2, 32), (3, 144, 90, 2, 16)])
+                                          (5, 129, 129, 2, 64), (4, 70, 130, 2, 32), (3, 144, 90, 2, 16),
+                                          # >= 1024 (sentence, head) items: the backward's split form when the forward result is passed
+                                          (300, 34, 34, 4, 64), (260, 20, 48, 4, 32), (600, 16, 9, 2, 16)])
 def test_attention_packed_rows(ops, B, nq, nk, h, dk):
     """nast_mha_*_varlen_f32 on packed rows == the padded call with a key-padding mask, on the real rows (forward and
     all three gradients); sentences of length 1 and of full width included."""
@@ -541,21 +546,22 @@ def test_attention_packed_rows(ops, B, nq, nk, h, dk):
     pair = ops.PackedPair(pq, pk)
     qp, kp, vp = ops.pack_rows(dev(q), pq), ops.pack_rows(dev(k), pk), ops.pack_rows(dev(v), pk)
     out, lse = ops.mha_fwd_packed(qp, kp, vp, pair, h)
-    dq, dk_, dv = ops.mha_bwd_packed(qp, kp, vp, pair, h, ops.pack_rows(dev(R), pq), lse)
     qmask = (torch.arange(nq)[None] < ql[:, None]).unsqueeze(-1)
     kmask = (torch.arange(nk)[None] < kl[:, None]).unsqueeze(-1)
-    for t, ps_ in ((out, pq), (dq, pq), (dk_, pk), (dv, pk)):         # buffer padding rows come back as exact zeros
-        assert t.shape[0] == ps_.rows and float(t[ps_.total:].abs().max()) == 0.0
     relclose(ops.unpack_rows(out, pq), yref * qmask)
-    relclose(ops.unpack_rows(dq, pq), qr.grad * qmask)
-    relclose(ops.unpack_rows(dk_, pk), kr.grad * kmask)
-    relclose(ops.unpack_rows(dv, pk), vr.grad * kmask)
+    for with_out in (None, out):       # without the forward result: two-phase kernel; with it: delta from dO * O, halves side by side
+        dq, dk_, dv = ops.mha_bwd_packed(qp, kp, vp, pair, h, ops.pack_rows(dev(R), pq), lse, with_out)
+        for t, ps_ in ((out, pq), (dq, pq), (dk_, pk), (dv, pk)):         # buffer padding rows come back as exact zeros
+            assert t.shape[0] == ps_.rows and float(t[ps_.total:].abs().max()) == 0.0
+        relclose(ops.unpack_rows(dq, pq), qr.grad * qmask)
+        relclose(ops.unpack_rows(dk_, pk), kr.grad * kmask)
+        relclose(ops.unpack_rows(dv, pk), vr.grad * kmask)
 
 
-@pytest.mark.parametrize("n,h,dk", [(33, 4, 64), (129, 2, 64), (100, 2, 32)])
-def test_attention_packed_rows_causal(ops, n, h, dk):
-    """causal flag of the packed attention entry points == the padded call with the causal mask, on the real rows"""
-    B = 5
+@pytest.mark.parametrize("n,h,dk,B", [(33, 4, 64, 5), (129, 2, 64, 5), (100, 2, 32, 5), (33, 4, 64, 280)])
+def test_attention_packed_rows_causal(ops, n, h, dk, B):
+    """causal flag of the packed attention entry points == the padded call with the causal mask, on the real rows
+    (280 sentences x 4 heads: the backward's split form)"""
     g = torch.Generator().manual_seed(5)
     D = h * dk
     ln = torch.randint(1, n + 1, (B,), generator=g); ln[0], ln[-1] = n, 1
@@ -570,11 +576,12 @@ def test_attention_packed_rows_causal(ops, n, h, dk):
     pair = ops.PackedPair(ps, ps, causal=True)
     qp, kp, vp = (ops.pack_rows(dev(t), ps) for t in (q, k, v))
     out, lse = ops.mha_fwd_packed(qp, kp, vp, pair, h)
-    dq, dk_, dv = ops.mha_bwd_packed(qp, kp, vp, pair, h, ops.pack_rows(dev(R), ps), lse)
     relclose(ops.unpack_rows(out, ps), yref * live)
-    relclose(ops.unpack_rows(dq, ps), qr.grad * live)
-    relclose(ops.unpack_rows(dk_, ps), kr.grad * live)
-    relclose(ops.unpack_rows(dv, ps), vr.grad * live)
+    for with_out in (None, out):
+        dq, dk_, dv = ops.mha_bwd_packed(qp, kp, vp, pair, h, ops.pack_rows(dev(R), ps), lse, with_out)
+        relclose(ops.unpack_rows(dq, ps), qr.grad * live)
+        relclose(ops.unpack_rows(dk_, ps), kr.grad * live)
+        relclose(ops.unpack_rows(dv, ps), vr.grad * live)
 
 
 @pytest.mark.parametrize("B,width,zero_frac", [(1, 5, 0.0), (7, 9, 0.3), (513, 33, 0.0), (2048, 17, 0.1), (64, 64, 0.0)])
