@@ -2,6 +2,8 @@
 // kept in registers; HBM-bound: 8d bytes/row forward).
 #include <initializer_list>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 #define LN_MAX_PER_LANE 16
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256) void nast_ln_fwd_vec_kernel(const float* __res
 // 16 wavefronts per workgroup and at most one workgroup per CU: enough rows in flight to stream at HBM rate while
 // each column of dgamma / dbeta receives <= 256 atomic adds (same-address fp32 atomics serialise at ~20 G/s)
 #define LN_BWD_WAVES 16
-template <int NV>
+template <int NV, int RB>
 __global__ __launch_bounds__(1024) void nast_ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* __restrict__ dx,
@@ -178,38 +180,58 @@ __global__ __launch_bounds__(1024) void nast_ln_bwd_vec_kernel(const float* __re
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int r = blockIdx.x * LN_BWD_WAVES + wave; r < rows_out; r += gridDim.x * LN_BWD_WAVES) {
-    const int64_t ir = ln_in_row(r, grp, grp_stride, grp_off);
-    const float* xr = x + ir * d;
-    const float* gr = dy + (int64_t)r * d;
-    const float mu = mean[r], rs = rstd[r];
-    float4 xh[NV], g[NV], ad[NV];
-    float s1 = 0.f, s2 = 0.f;
+  // RB rows of a wavefront are in flight together (all their loads are requested before the first is used): at the training
+  // step's ~10k rows a wavefront owns 2-3 rows, and one row at a time meant 2-3 dependent HBM round trips per launch
+  const int stride = gridDim.x * LN_BWD_WAVES;
+  for (int r0 = blockIdx.x * LN_BWD_WAVES + wave; r0 < rows_out; r0 += stride * RB) {
+    float4 dyv[RB][NV], xv[RB][NV], ad[RB][NV];
+    float mu[RB], rs[RB];
+    int64_t ir[RB];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = 4 * lane + 256 * i;
-      const bool ok = c < d;
-      const float4 dyv = ok ? *reinterpret_cast<const float4*>(gr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 xv = ok ? *reinterpret_cast<const float4*>(xr + c) : make_float4(mu, mu, mu, mu);
-      ad[i] = (ok && dx_add) ? *reinterpret_cast<const float4*>(dx_add + ir * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs; xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
-      g[i].x = dyv.x * gam[i].x; g[i].y = dyv.y * gam[i].y; g[i].z = dyv.z * gam[i].z; g[i].w = dyv.w * gam[i].w;
-      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
-      s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
-      ag[i].x += dyv.x * xh[i].x; ag[i].y += dyv.y * xh[i].y; ag[i].z += dyv.z * xh[i].z; ag[i].w += dyv.w * xh[i].w;
-      ab[i].x += dyv.x; ab[i].y += dyv.y; ab[i].z += dyv.z; ab[i].w += dyv.w;
+    for (int k = 0; k < RB; ++k) {
+      const int r = r0 + k * stride;
+      const bool rok = r < rows_out;
+      ir[k] = rok ? ln_in_row(r, grp, grp_stride, grp_off) : 0;
+      mu[k] = rok ? mean[r] : 0.f;
+      rs[k] = rok ? rstd[r] : 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        const bool ok = rok && c < d;
+        dyv[k][i] = ok ? *reinterpret_cast<const float4*>(dy + (int64_t)r * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[k][i] = ok ? *reinterpret_cast<const float4*>(x + ir[k] * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ad[k][i] = (ok && dx_add) ? *reinterpret_cast<const float4*>(dx_add + ir[k] * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
-    s1 = wave_sum(s1) / d;
-    s2 = wave_sum(s2) / d;
-    float* dxr = dx + ir * d;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = 4 * lane + 256 * i;
-      if (c < d) {
-        float4 o;
-        o.x = rs * (g[i].x - s1 - xh[i].x * s2) + ad[i].x; o.y = rs * (g[i].y - s1 - xh[i].y * s2) + ad[i].y;
-        o.z = rs * (g[i].z - s1 - xh[i].z * s2) + ad[i].z; o.w = rs * (g[i].w - s1 - xh[i].w * s2) + ad[i].w;
-        *reinterpret_cast<float4*>(dxr + c) = o;
+    for (int k = 0; k < RB; ++k) {
+      if (r0 + k * stride >= rows_out) break;     // (uniform for the wavefront)
+      float4 xh[NV], g[NV];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const bool ok = 4 * lane + 256 * i < d;
+        const float m = ok ? mu[k] : 0.f;          // (columns past d hold zeros and must stay zeros)
+        xh[i].x = (xv[k][i].x - m) * rs[k]; xh[i].y = (xv[k][i].y - m) * rs[k];
+        xh[i].z = (xv[k][i].z - m) * rs[k]; xh[i].w = (xv[k][i].w - m) * rs[k];
+        g[i].x = dyv[k][i].x * gam[i].x; g[i].y = dyv[k][i].y * gam[i].y; g[i].z = dyv[k][i].z * gam[i].z; g[i].w = dyv[k][i].w * gam[i].w;
+        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+        ag[i].x += dyv[k][i].x * xh[i].x; ag[i].y += dyv[k][i].y * xh[i].y; ag[i].z += dyv[k][i].z * xh[i].z; ag[i].w += dyv[k][i].w * xh[i].w;
+        ab[i].x += dyv[k][i].x; ab[i].y += dyv[k][i].y; ab[i].z += dyv[k][i].z; ab[i].w += dyv[k][i].w;
+      }
+      s1 = wave_sum(s1) / d;
+      s2 = wave_sum(s2) / d;
+      float* dxr = dx + ir[k] * d;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < d) {
+          float4 o;
+          o.x = rs[k] * (g[i].x - s1 - xh[i].x * s2) + ad[k][i].x; o.y = rs[k] * (g[i].y - s1 - xh[i].y * s2) + ad[k][i].y;
+          o.z = rs[k] * (g[i].z - s1 - xh[i].z * s2) + ad[k][i].z; o.w = rs[k] * (g[i].w - s1 - xh[i].w * s2) + ad[k][i].w;
+          *reinterpret_cast<float4*>(dxr + c) = o;
+        }
       }
     }
   }
@@ -283,20 +305,24 @@ extern "C" int nast_layernorm_bwd_f32(const float* dy, const float* x, const flo
   const bool vec = ln_vec_ok(d, {dy, x, gamma, dx, dx_add});
   if (vec) {
     int blocks = (rows_out + LN_BWD_WAVES - 1) / LN_BWD_WAVES;
-    if (blocks > 256) blocks = 256;
+    // every workgroup ends with 2 d atomic adds into the same 2 d floats; measured at 9920 rows x 256 (tools/ln_bench.py): the
+    // streaming part takes 9.0 us on 256 workgroups / 10.2 on 128, the atomic tail 4.0 / 1.5 us -- 128 wins until the rows double
+    static const int forced = [] { const char* e = getenv("NAST_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();   // tuning aid
+    const int max_blocks = forced > 0 ? forced : (rows_out >= 16384 ? 256 : 128);
+    if (blocks > max_blocks) blocks = max_blocks;
     const size_t lds = (size_t)2 * LN_BWD_WAVES * d * sizeof(float);
     const dim3 grid(blocks), block(LN_BWD_WAVES * 64);
     if (d <= 256) {
-      hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<1>, grid, block, lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+      hipLaunchKernelGGL((nast_ln_bwd_vec_kernel<1, 3>), grid, block, lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
     } else if (d <= 512) {
-      hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<2>, grid, block, lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+      hipLaunchKernelGGL((nast_ln_bwd_vec_kernel<2, 2>), grid, block, lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
     } else {
       static bool attr_set = false;
       if (!attr_set) {
-        hipFuncSetAttribute((const void*)nast_ln_bwd_vec_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LN_BWD_WAVES * 1024 * 4);
+        hipFuncSetAttribute((const void*)nast_ln_bwd_vec_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LN_BWD_WAVES * 1024 * 4);
         attr_set = true;
       }
-      hipLaunchKernelGGL(nast_ln_bwd_vec_kernel<4>, grid, block, lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
+      hipLaunchKernelGGL((nast_ln_bwd_vec_kernel<4, 1>), grid, block, lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dx_add, rows_out, d, grp, grp_stride, grp_off);
     }
   } else {
     int blocks = (rows_out + 3) / 4;

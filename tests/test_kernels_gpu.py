@@ -140,7 +140,9 @@ def test_gemm_relu_and_matmul_nn(ops):
     relclose(y, torch.matmul(s, E)); relclose(sg.grad, sr.grad); relclose(Eg.grad, Er.grad)
 
 
-@pytest.mark.parametrize("rows,d", [(7, 32), (1088, 256), (100, 1024), (9, 48)])
+@pytest.mark.parametrize("rows,d", [(7, 32), (1088, 256), (100, 1024), (9, 48),
+                                    # more rows than one pass of the backward grid holds (4096 x rows-in-flight per wavefront), ragged last pass
+                                    (13001, 256), (9001, 512), (4100, 1024), (12290, 64)])
 def test_layernorm(ops, rows, d):
     g = torch.Generator().manual_seed(rows + d)
     x = torch.randn(rows, d, generator=g) * 2 + 0.5
