@@ -270,7 +270,7 @@ def main():
                                               "unit": "sentences/s"}
 
         def timed(fn, n):
-            for _ in range(2):
+            for _ in range(4):       # (these legs follow the 64-sentence and graph legs: let the caching allocator settle again)
                 fn(0)
             torch.cuda.synchronize()
             t = time.perf_counter()
