@@ -35,6 +35,16 @@ __device__ __forceinline__ bf16x8 pack_bf16(const float4& lo, const float4& hi) 
 #define NAST_GEMM_LAB 0      // ablation builds only (tools/gemm_lab.sh): 1 = no global loads after the first K-tile, 2 = no LDS stores
 #endif                       // after the first, 4 = fragments read once per K-tile only; results are then wrong by construction
 
+#ifdef GEMM_STAMPS   // debug build only (tools/gemm_stamps.py): per-workgroup s_memtime stamps of the tiled kernel's segments
+__device__ unsigned long long g_gemm_stamps[8192 * 8];
+#define GEMM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_gemm_stamps[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int nast_gemm_stamps_read(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * n);
+}
+#else
+#define GEMM_STAMP(k) do { } while (0)
+#endif
+
 struct GemmLaunch {
   nast_gemm_desc d[NAST_GEMM_MAX_GROUP];
   int tile_start[NAST_GEMM_MAX_GROUP + 1];
@@ -204,12 +214,15 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
     tile_load<BN, BK, BKC, FAST>(Bp, D.ldb, vb && ((reinterpret_cast<uintptr_t>(Bp) & 15) == 0), n0, N, kt * BK, K, rb);
   };
 
+  GEMM_STAMP(1);
   if (steps > 0) {
     issue(0);
     tile_store<BM, BK, AKC>(smem, ra);
     tile_store<BN, BK, BKC>(smem + GA::SZ, rb);
   }
+  GEMM_STAMP(2);
   __syncthreads();
+  GEMM_STAMP(3);
 
   for (int step = 0; step < steps; ++step) {
     const int cur = step & 1;
@@ -309,6 +322,7 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
     }
     __syncthreads();
   }
+  GEMM_STAMP(4);
 
   // ---- epilogue ----
   if (!AKC) {
@@ -417,6 +431,7 @@ template <int BM, int BN, int BK, bool FAST, bool BF16>
 __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) {
   using GA = TileGeom<BM, BK>;
   using GB = TileGeom<BN, BK>;
+  GEMM_STAMP(0);
   __shared__ __attribute__((aligned(16))) float smem[2 * (GA::SZ + GB::SZ)];
   // ---- which problem / tile / k-slice ----
   // Optional XCD-contiguous order (NAST_GEMM_XCD=1): workgroups are dealt round-robin over the 8 XCDs, so making the
@@ -455,6 +470,7 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
   else if (a_kc && !b_kc) gemm_tile<BM, BN, BK, true, false, FAST, BF16>(D, tm, tn, kz, per, smem);   // dx = dy W, soft x E
   else if (!a_kc && !b_kc) gemm_tile<BM, BN, BK, false, false, FAST, BF16>(D, tm, tn, kz, per, smem); // dW = dy^T x
   else gemm_tile<BM, BN, BK, false, true, FAST, BF16>(D, tm, tn, kz, per, smem);
+  GEMM_STAMP(5);
 }
 
 // -------------------------------------------------------------------------------------------------
