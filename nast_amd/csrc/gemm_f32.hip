@@ -385,7 +385,7 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
           if (col_ok && row < M) {
             float4* cp = reinterpret_cast<float4*>(Cp + (int64_t)row * ldc + col);
             if (flags & NAST_GEMM_ACCUM) { const float4 c0 = *cp; v.x += c0.x; v.y += c0.y; v.z += c0.z; v.w += c0.w; }
-            *cp = v;
+            *cp = v;   // (a non-temporal store here: 2-6 % off an isolated launch on rotated operands, nothing off the step)
           }
         }
       }
