@@ -224,6 +224,17 @@ int nast_align_lse_bwd_f32(const float* cost0, const float* cost, const int64_t*
 int nast_pack_index_i64(const int64_t* lengths, int B, int width, int total, int rows, int64_t* off, int32_t* off32,
                         int32_t* len32, int64_t* b_of, int64_t* pos, int64_t* idx, int64_t* idx_p, int* bad, void* stream);
 
+/* Rows between the padded [B * width, d] layout and the packed one (ops.pack_rows / ops.unpack_rows and their backward
+ * passes) -- no counterpart in the reference (see nast_pack_index_i64).  Both are gathers, one launch, no zero-fill:
+ *   gather:  y[r] = x[idx[r]] for r < n_idx, zeros for n_idx <= r < rows_out   (x, y: row pitches ldx, ldy >= d)
+ *   unpack:  y[b * width + p] = p < len[b] ? xp[off[b] + p] : zeros            (off int64 [B], len int32 [B]; xp has rows_in
+ *            rows, a source row beyond them reads as zeros) */
+int nast_rows_gather_f32(const float* x, int64_t ldx, const int64_t* idx, int n_idx, int rows_out, int d, float* y, int64_t ldy,
+                         void* stream);
+int nast_rows_unpack_f32(const float* xp, int64_t ldx, int rows_in, const int64_t* off, const int32_t* len, int B, int width, int d,
+                         float* y, int64_t ldy, void* stream);
+
+
 /* ------------------------------------------------------------------------------------------------
  * NoiseLayer on the device (noise.py:60-194): blank -> add -> dropout/repeat of
  * NoiseLayer.forward (:60-74) for a whole [S, B] time-major batch of ids, one lane per sentence.  Each stage is

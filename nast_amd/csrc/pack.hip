@@ -81,3 +81,75 @@ extern "C" int nast_pack_index_i64(const int64_t* lengths, int B, int width, int
   NAST_CHECK_LAUNCH("nast_pack_index_i64");
   return NAST_OK;
 }
+
+// ---- moving rows between the padded [B * width, d] layout and the packed one ------------------------------------
+// Both directions are gathers (every output row knows its source), so neither needs the zero-fill + scatter pair
+// (torch: zeros + index_copy / index_add) that the autograd formulas of index_select / index_copy produce: one launch,
+// each byte written once.  One wavefront per output row, 16-byte accesses when the pitches allow.
+template <bool VEC>
+__global__ __launch_bounds__(256) void nast_rows_gather_kernel(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ idx,
+                                                               int n_idx, int rows_out, int d, float* __restrict__ y, int64_t ldy) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows_out) return;
+  float* yr = y + (int64_t)r * ldy;
+  if (r >= n_idx) {                              // rows past the index list: zeros
+    if (VEC) for (int c = 4 * lane; c < d; c += 256) *reinterpret_cast<float4*>(yr + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else for (int c = lane; c < d; c += 64) yr[c] = 0.f;
+    return;
+  }
+  const float* xr = x + idx[r] * ldx;
+  if (VEC) for (int c = 4 * lane; c < d; c += 256) *reinterpret_cast<float4*>(yr + c) = *reinterpret_cast<const float4*>(xr + c);
+  else for (int c = lane; c < d; c += 64) yr[c] = xr[c];
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void nast_rows_unpack_kernel(const float* __restrict__ xp, int64_t ldx, const int64_t* __restrict__ off,
+                                                               const int32_t* __restrict__ len, int B, int width, int d,
+                                                               int rows_in, float* __restrict__ y, int64_t ldy) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (int64_t)B * width) return;
+  const int b = (int)(r / width), p = (int)(r % width);
+  float* yr = y + r * ldy;
+  const int64_t src = off[b] + p;
+  if (p >= len[b] || src >= rows_in) {           // a padded position of the [B, width] layout (or, after a length / total
+                                                 // mismatch that nast_pack_index_i64 has flagged, a row the buffer does not have)
+    if (VEC) for (int c = 4 * lane; c < d; c += 256) *reinterpret_cast<float4*>(yr + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else for (int c = lane; c < d; c += 64) yr[c] = 0.f;
+    return;
+  }
+  const float* xr = xp + src * ldx;
+  if (VEC) for (int c = 4 * lane; c < d; c += 256) *reinterpret_cast<float4*>(yr + c) = *reinterpret_cast<const float4*>(xr + c);
+  else for (int c = lane; c < d; c += 64) yr[c] = xr[c];
+}
+
+static bool rows_vec_ok(const void* a, const void* b, int64_t lda, int64_t ldb, int d) {
+  return (d & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0;
+}
+
+extern "C" int nast_rows_gather_f32(const float* x, int64_t ldx, const int64_t* idx, int n_idx, int rows_out, int d, float* y,
+                                    int64_t ldy, void* stream) {
+  NAST_REQUIRE(n_idx >= 0 && rows_out >= n_idx && d >= 1 && ldx >= d && ldy >= d, "nast_rows_gather_f32: bad sizes n_idx=%d rows_out=%d d=%d", n_idx, rows_out, d);
+  if (rows_out == 0) return NAST_OK;
+  NAST_REQUIRE(y && (n_idx == 0 || (x && idx)), "nast_rows_gather_f32: NULL pointer");
+  const dim3 grid((rows_out + 3) / 4), block(256);
+  if (rows_vec_ok(x, y, ldx, ldy, d)) hipLaunchKernelGGL(nast_rows_gather_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, idx, n_idx, rows_out, d, y, ldy);
+  else hipLaunchKernelGGL(nast_rows_gather_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, idx, n_idx, rows_out, d, y, ldy);
+  NAST_CHECK_LAUNCH("nast_rows_gather_f32");
+  return NAST_OK;
+}
+
+extern "C" int nast_rows_unpack_f32(const float* xp, int64_t ldx, int rows_in, const int64_t* off, const int32_t* len, int B, int width,
+                                    int d, float* y, int64_t ldy, void* stream) {
+  NAST_REQUIRE(B >= 0 && width >= 0 && d >= 1 && ldx >= d && ldy >= d && rows_in >= 0, "nast_rows_unpack_f32: bad sizes B=%d width=%d d=%d", B, width, d);
+  const int64_t rows = (int64_t)B * width;
+  if (rows == 0) return NAST_OK;
+  NAST_REQUIRE(rows <= (int64_t)4 * 0x7fffffff, "nast_rows_unpack_f32: too many rows");
+  NAST_REQUIRE(xp && off && len && y, "nast_rows_unpack_f32: NULL pointer");
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (rows_vec_ok(xp, y, ldx, ldy, d)) hipLaunchKernelGGL(nast_rows_unpack_kernel<true>, grid, block, 0, (hipStream_t)stream, xp, ldx, off, len, B, width, d, rows_in, y, ldy);
+  else hipLaunchKernelGGL(nast_rows_unpack_kernel<false>, grid, block, 0, (hipStream_t)stream, xp, ldx, off, len, B, width, d, rows_in, y, ldy);
+  NAST_CHECK_LAUNCH("nast_rows_unpack_f32");
+  return NAST_OK;
+}

@@ -642,13 +642,64 @@ def packed_of(mask, x, dk=None):
     return ps
 
 
+def _rows_gather(x2, idx, n_idx, rows_out):
+    """y[r] = x2[idx[r]] for r < n_idx, zeros up to rows_out (x2: 2-d, unit stride along the row)"""
+    y = torch.empty(rows_out, x2.shape[1], device=x2.device, dtype=F32)
+    call("nast_rows_gather_f32", _p(x2), x2.stride(0), _p(idx), n_idx, rows_out, x2.shape[1], _p(y), y.stride(0), _stream())
+    return y
+
+
+def _rows_unpack(xp, ps):
+    """y[b * width + p] = xp[off[b] + p] for p < len[b], zeros elsewhere (xp: 2-d, unit stride along the row)"""
+    y = torch.empty(ps.B * ps.width, xp.shape[1], device=xp.device, dtype=F32)
+    call("nast_rows_unpack_f32", _p(xp), xp.stride(0), xp.shape[0], _p(ps.off), _p(ps.len32), ps.B, ps.width, xp.shape[1], _p(y), y.stride(0),
+         _stream())
+    return y
+
+
+def _rows_2d(t):
+    t = t.reshape(-1, t.shape[-1])
+    return t if t.stride(1) == 1 and t.stride(0) >= t.shape[1] else t.contiguous()
+
+
+class PackRowsFn(torch.autograd.Function):
+    """index_select by ps.idx_p; the backward pass is the gather `unpack` instead of zeros + index_add"""
+
+    @staticmethod
+    def forward(ctx, x, ps):
+        ctx.ps, ctx.xshape = ps, x.shape
+        return _rows_gather(_rows_2d(x), ps.idx_p, ps.rows, ps.rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rows_unpack(_rows_2d(g), ctx.ps).view(ctx.xshape), None
+
+
+class UnpackRowsFn(torch.autograd.Function):
+    """packed rows to their [B, width] positions, zeros elsewhere, in one launch; backward = gather by ps.idx, zero tail"""
+
+    @staticmethod
+    def forward(ctx, xp, ps):
+        ctx.ps, ctx.rows = ps, xp.shape[0]
+        return _rows_unpack(_rows_2d(xp), ps).view(ps.B, ps.width, xp.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        ps = ctx.ps
+        return _rows_gather(_rows_2d(g), ps.idx, ps.total, ctx.rows), None
+
+
 def pack_rows(x, ps):
     """[B, n, d] -> [ps.rows, d]  (ps.total real rows, then copies of row 0 as padding)"""
+    if x.is_cuda and x.dtype == F32:
+        return PackRowsFn.apply(x, ps)
     return x.reshape(-1, x.shape[-1]).index_select(0, ps.idx_p)
 
 
 def unpack_rows(xp, ps):
     """[ps.rows, d] -> [B, n, d], zeros at the padded positions"""
+    if xp.is_cuda and xp.dtype == F32:
+        return UnpackRowsFn.apply(xp, ps)
     out = torch.zeros(ps.B * ps.width, xp.shape[-1], device=xp.device, dtype=xp.dtype)
     return out.index_copy(0, ps.idx, xp[:ps.total]).view(ps.B, ps.width, xp.shape[-1])
 

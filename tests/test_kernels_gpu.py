@@ -586,6 +586,36 @@ def test_attention_packed_rows_causal(ops, n, h, dk, B):
         relclose(ops.unpack_rows(dv, ps), vr.grad * live)
 
 
+@pytest.mark.parametrize("B,width,d,zero_frac", [(1, 5, 8, 0.0), (7, 9, 6, 0.3), (513, 33, 256, 0.0), (300, 17, 64, 0.1), (5, 130, 1024, 0.0)])
+def test_pack_unpack_rows_equal_torch_index_ops(ops, B, width, d, zero_frac):
+    """ops.pack_rows / ops.unpack_rows (gather kernels, forward and backward) against index_select / zeros + index_copy and
+    what autograd makes of those -- plain copies, so bit-exact; also a strided one-column view as PackedSoft.column passes it."""
+    g = torch.Generator().manual_seed(B * 7 + width)
+    lengths = torch.randint(1, width + 1, (B,), generator=g)
+    lengths[torch.rand(B, generator=g) < zero_frac] = 0
+    lengths[0] = width
+    lengths = lengths.cuda()
+    ps = ops.PackedSeq(lengths, width, int(lengths.sum()))
+    x = torch.randn(B, width, d, generator=g).cuda()
+    Rp = torch.randn(ps.rows, d, generator=g).cuda()
+    Ru = torch.randn(B, width, d, generator=g).cuda()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = ops.pack_rows(xa, ps)
+    yb = xb.reshape(-1, d).index_select(0, ps.idx_p)
+    assert torch.equal(ya, yb)
+    Rp0 = Rp.clone(); Rp0[ps.total:] = 0                      # (the rows past `total` carry zero gradient in the model)
+    (ya * Rp0).sum().backward(); (yb * Rp0).sum().backward()
+    assert torch.equal(xa.grad, xb.grad)
+    pa, pb = ya.detach().clone().requires_grad_(True), ya.detach().clone().requires_grad_(True)
+    ua = ops.unpack_rows(pa, ps)
+    ub = torch.zeros(B * width, d, device="cuda").index_copy(0, ps.idx, pb[:ps.total]).view(B, width, d)
+    assert torch.equal(ua, ub)
+    (ua * Ru).sum().backward(); (ub * Ru).sum().backward()
+    assert torch.equal(pa.grad, pb.grad)
+    col = ya.detach()[:, d // 2:d // 2 + 1]                     # strided [rows, 1] view
+    assert torch.equal(ops.unpack_rows(col, ps), torch.zeros(B * width, 1, device="cuda").index_copy(0, ps.idx, col[:ps.total]).view(B, width, 1))
+
+
 @pytest.mark.parametrize("B,width,zero_frac", [(1, 5, 0.0), (7, 9, 0.3), (513, 33, 0.0), (2048, 17, 0.1), (64, 64, 0.0)])
 def test_pack_index_kernel_equals_torch_maps(ops, B, width, zero_frac):
     """nast_pack_index_i64 (one launch) against the torch formulation of ops.PackedSeq -- integer maps, bit-exact."""
