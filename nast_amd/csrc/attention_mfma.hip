@@ -35,6 +35,10 @@ extern "C" int nast_attn_stamps_read(unsigned long long* host, int n) {
 #define ATTN_STAMP(k) do { } while (0)
 #endif
 
+#ifndef ATTN_LD_PAD
+#define ATTN_LD_PAD 4      // (lab builds: 8 makes the 16-byte row reads conflict-free and the 4-byte column reads 2-way)
+#endif
+
 namespace {
 
 template <int DK>
@@ -263,7 +267,7 @@ __device__ __forceinline__ void stage_rows_flag(float* __restrict__ dst, const f
 // per CU runs 35.6 / 62.8 us where this form takes 30.9 / 41.8 at 32 / 34 positions, 512 sentences x 4 heads.)
 template <int DK, int NT, bool SPLIT>
 __global__ __launch_bounds__(256, NT <= 3 ? 3 : 2) void nast_mha_bwd_mfma_kernel(const AttnArgs P) {
-  constexpr int NS = DK / 4, NCT = (DK + 15) / 16, LD = DK + 4;
+  constexpr int NS = DK / 4, NCT = (DK + 15) / 16, LD = DK + ATTN_LD_PAD;
   __shared__ __attribute__((aligned(16))) float Ks[NT * 16 * LD];
   __shared__ __attribute__((aligned(16))) float Vs[NT * 16 * LD];
   __shared__ __attribute__((aligned(16))) float Qs[NT * 16 * LD];

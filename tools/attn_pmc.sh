@@ -3,7 +3,7 @@
 # usage: [MODE=packed] [NAST_ATTN_BWD_FORM=n] tools/attn_pmc.sh "<B> <n>"
 cd /tmp && export TMPDIR=/tmp
 out=/tmp/attn_pmc; rm -rf $out
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/attn_bench.py $1 256 4 20 bwd $MODE > /dev/null 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/tools/attn_bench.py $1 256 4 20 bwd $MODE > /dev/null 2>&1 || exit 1
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections

@@ -8,6 +8,7 @@ Derivations as in profiles/r1_gemm_pmc.txt (checked there against the event-time
   cycles           = GRBM_GUI_ACTIVE / 8                     (the counter sums the 8 XCDs)
   MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)
   waves per SIMD   = 4 x SQ_WAVE_CYCLES / (1024 x cycles)    (SQ wave counters tick in quad-cycles)
+  LDS conflict     = SQ_LDS_BANK_CONFLICT / (256 CUs x cycles)   (extra LDS-array cycles per CU cycle)
 """
 import csv
 import glob
@@ -44,7 +45,9 @@ def main():
         mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc)
         wv = 4.0 * c.get("SQ_WAVE_CYCLES", 0.0) / (1024.0 * cyc)
         wi = c.get("SQ_WAIT_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 0.0), 1.0)
-        lc = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c.get("SQ_BUSY_CYCLES", 0.0), 1.0)
+        # extra LDS cycles per CU cycle.  (Until round 2 this column divided by SQ_BUSY_CYCLES, which ticks per shader engine,
+        # not per CU: it overstated the share 8-10x -- 20.7 % for the attention backward where the CUs spend 2.2 %.)
+        lc = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / (256.0 * cyc)
         print(f"{k[:58]:58s} {nl:8d} {100 * cyc / total:12.1f} {100 * mf:11.1f} {wv:10.2f} {100 * wi:11.1f} {100 * lc:14.2f}")
 
 
