@@ -192,7 +192,8 @@ def ref_attention(q, k, v, mask, h):
                                                 (2, 144, 144, 1, 64, "none"), (2, 65, 129, 2, 64, "causal"), (2, 130, 40, 2, 64, "pad"),
                                                 (2, 150, 150, 1, 64, "pad"),
                                                 # >= 1024 (sentence, head) items: the backward's split form (delta from dO * O)
-                                                (260, 33, 33, 4, 64, "pad"), (300, 20, 30, 4, 32, "causal"), (520, 12, 16, 2, 16, "pad")])
+                                                (260, 33, 33, 4, 64, "pad"), (300, 20, 30, 4, 32, "causal"), (520, 12, 16, 2, 16, "pad"),
+                                                (600, 9, 11, 2, 8, "pad"), (1030, 40, 48, 1, 64, "none")])
 def test_attention(ops, B, nq, nk, h, dk, kind):
     g = torch.Generator().manual_seed(B * 100 + nq)
     D = h * dk
