@@ -223,159 +223,176 @@ def main():
 
     also = None
     if world == 1 and B > 64 and not a.no_also:
-        # the same step at the reference's batch size (64 sentences)
-        small = [synth_incoming(64, L, cfg["V"], 5000 + i, "cuda") for i in range(4)]
-        for i in range(3):
-            model.f_step(small[i % 4], 1.0, use_inference_z=True)
-        torch.cuda.synchronize()
-        n_small = min(a.steps, 10)
-        t1 = time.perf_counter()
-        for i in range(n_small):
-            model.f_step(small[i % 4], 1.0, use_inference_z=True)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / n_small
-        also = {"bs64": {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_small}}
+        # (optional legs: a failure in one of them must not cost the headline line; what was measured so far is kept)
+        also = {}
+        try:
+            # the same step at the reference's batch size (64 sentences)
+            small = [synth_incoming(64, L, cfg["V"], 5000 + i, "cuda") for i in range(4)]
+            for i in range(3):
+                model.f_step(small[i % 4], 1.0, use_inference_z=True)
+            torch.cuda.synchronize()
+            n_small = min(a.steps, 10)
+            t1 = time.perf_counter()
+            for i in range(n_small):
+                model.f_step(small[i % 4], 1.0, use_inference_z=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / n_small
+            also["bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_small}
 
-        def graphed(m, data, n, which="f_step"):
-            """the same step replayed from one HIP graph (nast_amd/graph.py): 2 eager fixed-width steps, capture, then timing"""
-            m.graph_steps = True
-            step = getattr(m, which)
-            try:
-                for i in range(4):
-                    step(data[i % 4], 1.0, use_inference_z=True)
+            def graphed(m, data, n, which="f_step"):
+                """the same step replayed from one HIP graph (nast_amd/graph.py): 2 eager fixed-width steps, capture, then timing"""
+                m.graph_steps = True
+                step = getattr(m, which)
+                try:
+                    for i in range(4):
+                        step(data[i % 4], 1.0, use_inference_z=True)
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for i in range(n):
+                        step(data[i % 4], 1.0, use_inference_z=True)
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t) / n
+                finally:
+                    m.graph_steps = False
+
+            dtg = graphed(model, small, max(n_small, 10))
+            also["bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3),
+                                  "note": "whole f_step replayed from one HIP graph (Seq2seq.graph_steps = True)"}
+            # the discriminator step at 64 sentences, eager and replayed, and the reference's schedule (10 d_step : 5 f_step) on both
+            for i in range(3):
+                model.d_step(small[i % 4], 1.0, use_inference_z=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n_small):
+                model.d_step(small[i % 4], 1.0, use_inference_z=True)
+            torch.cuda.synchronize()
+            dtd = (time.perf_counter() - t1) / n_small
+            dtdg = graphed(model, small, max(n_small, 10), "d_step")
+            also["bs64_d_step"] = {"ms_per_step": round(dtd * 1e3, 3), "ms_per_step_graph": round(dtdg * 1e3, 3)}
+            also["bs64_schedule_blend_10d_5f"] = {"value": round(15 * 64 / (10 * dtd + 5 * dt), 2), "value_graph": round(15 * 64 / (10 * dtdg + 5 * dtg), 2),
+                                                  "unit": "sentences/s"}
+
+            def timed(fn, n):
+                for _ in range(4):       # (these legs follow the 64-sentence and graph legs: let the caching allocator settle again)
+                    fn(0)
                 torch.cuda.synchronize()
                 t = time.perf_counter()
                 for i in range(n):
-                    step(data[i % 4], 1.0, use_inference_z=True)
+                    fn(i)
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t) / n
+
+            # the step without its optimizer, measured right behind the headline pass (clip + Adam skipped; forward + both backwards only)
+            step_fn = model.optimizer_F.clip_and_step
+            model.optimizer_F.clip_and_step = lambda max_norm=None, capturing=False: None
+            try:
+                dt_fb = timed(lambda i: model.f_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
             finally:
-                m.graph_steps = False
-
-        dtg = graphed(model, small, max(n_small, 10))
-        also["bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3),
-                              "note": "whole f_step replayed from one HIP graph (Seq2seq.graph_steps = True)"}
-        # the discriminator step at 64 sentences, eager and replayed, and the reference's schedule (10 d_step : 5 f_step) on both
-        for i in range(3):
-            model.d_step(small[i % 4], 1.0, use_inference_z=True)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(n_small):
-            model.d_step(small[i % 4], 1.0, use_inference_z=True)
-        torch.cuda.synchronize()
-        dtd = (time.perf_counter() - t1) / n_small
-        dtdg = graphed(model, small, max(n_small, 10), "d_step")
-        also["bs64_d_step"] = {"ms_per_step": round(dtd * 1e3, 3), "ms_per_step_graph": round(dtdg * 1e3, 3)}
-        also["bs64_schedule_blend_10d_5f"] = {"value": round(15 * 64 / (10 * dtd + 5 * dt), 2), "value_graph": round(15 * 64 / (10 * dtdg + 5 * dtg), 2),
-                                              "unit": "sentences/s"}
-
-        def timed(fn, n):
-            for _ in range(4):       # (these legs follow the 64-sentence and graph legs: let the caching allocator settle again)
-                fn(0)
+                model.optimizer_F.clip_and_step = step_fn
+            also["fwd_bwd_only"] = {"value": round(B / dt_fb, 2), "unit": "sentences/s", "ms_per_step": round(dt_fb * 1e3, 3), "batch": B}
+            # the discriminator step (seq2seq.py:551-642) on the same batches
+            dt = timed(lambda i: model.d_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
+            also["d_step"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B}
+            f_ms = elapsed / a.steps
+            # SURVEY.md section 8d: the reference schedule runs 10 d_step per 5 f_step (run.py:133-134)
+            also["schedule_blend_10d_5f"] = {"value": round(15 * B / (10 * dt + 5 * f_ms), 2), "unit": "sentences/s"}
+            # BASELINE.json configs[1]: simple alignment, YELP-shaped batch (64 sentences, len <= 16)
+            cfg1 = dict(V=9600, d=256, h=4, N=4, L=16, learnable=False)
+            m1 = build_model(cfg1, "cuda")
+            b1 = [synth_incoming(64, 16, 9600, 7000 + i, "cuda") for i in range(4)]
+            dt = timed(lambda i: m1.f_step(b1[i % 4], 1.0, use_inference_z=True), min(a.steps, 10))
+            also["configs1_simple_L16_bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3)}
+            dtg = graphed(m1, b1, 10)
+            also["configs1_simple_L16_bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3)}
+            del m1
+            # BASELINE configs[4] (stress shape: V=32000, d=1024, h=16, 8 layers, len<=128, learnable) at 64 sentences
+            cfg4 = dict(V=32000, d=1024, h=16, N=8, L=128, learnable=True)
+            m4 = build_model(cfg4, "cuda")
+            b4 = [synth_incoming(64, 128, 32000, 9000 + i, "cuda") for i in range(2)]
+            dt = timed(lambda i: m4.f_step(b4[i % 2], 1.0, use_inference_z=True), 3)
+            also["configs4_stress_L128_bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3)}
+            del m4, b4
+            torch.cuda.empty_cache()
+            if a.precision == "fp32":
+                # north_star's bf16 variant: GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 storage + accumulate), same step
+                _ops.set_gemm_precision("bf16")
+                dt = timed(lambda i: model.f_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
+                _ops.set_gemm_precision("fp32")
+                also["bf16_gemm_variant"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B,
+                                             "dtype": "bf16 MFMA operands, fp32 accumulate/storage"}
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            also["error"] = f"{type(e).__name__}: {e}"[:300]
+            model.graph_steps = False
+            _ops.set_gemm_precision(a.precision)
             torch.cuda.synchronize()
-            t = time.perf_counter()
-            for i in range(n):
-                fn(i)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / n
-
-        # the step without its optimizer, measured right behind the headline pass (clip + Adam skipped; forward + both backwards only)
-        step_fn = model.optimizer_F.clip_and_step
-        model.optimizer_F.clip_and_step = lambda max_norm=None, capturing=False: None
-        try:
-            dt_fb = timed(lambda i: model.f_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
-        finally:
-            model.optimizer_F.clip_and_step = step_fn
-        also["fwd_bwd_only"] = {"value": round(B / dt_fb, 2), "unit": "sentences/s", "ms_per_step": round(dt_fb * 1e3, 3), "batch": B}
-        # the discriminator step (seq2seq.py:551-642) on the same batches
-        dt = timed(lambda i: model.d_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
-        also["d_step"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B}
-        f_ms = elapsed / a.steps
-        # SURVEY.md section 8d: the reference schedule runs 10 d_step per 5 f_step (run.py:133-134)
-        also["schedule_blend_10d_5f"] = {"value": round(15 * B / (10 * dt + 5 * f_ms), 2), "unit": "sentences/s"}
-        # BASELINE.json configs[1]: simple alignment, YELP-shaped batch (64 sentences, len <= 16)
-        cfg1 = dict(V=9600, d=256, h=4, N=4, L=16, learnable=False)
-        m1 = build_model(cfg1, "cuda")
-        b1 = [synth_incoming(64, 16, 9600, 7000 + i, "cuda") for i in range(4)]
-        dt = timed(lambda i: m1.f_step(b1[i % 4], 1.0, use_inference_z=True), min(a.steps, 10))
-        also["configs1_simple_L16_bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3)}
-        dtg = graphed(m1, b1, 10)
-        also["configs1_simple_L16_bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3)}
-        del m1
-        # BASELINE configs[4] (stress shape: V=32000, d=1024, h=16, 8 layers, len<=128, learnable) at 64 sentences
-        cfg4 = dict(V=32000, d=1024, h=16, N=8, L=128, learnable=True)
-        m4 = build_model(cfg4, "cuda")
-        b4 = [synth_incoming(64, 128, 32000, 9000 + i, "cuda") for i in range(2)]
-        dt = timed(lambda i: m4.f_step(b4[i % 2], 1.0, use_inference_z=True), 3)
-        also["configs4_stress_L128_bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3)}
-        del m4, b4
-        torch.cuda.empty_cache()
-        if a.precision == "fp32":
-            # north_star's bf16 variant: GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 storage + accumulate), same step
-            _ops.set_gemm_precision("bf16")
-            dt = timed(lambda i: model.f_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
-            _ops.set_gemm_precision("fp32")
-            also["bf16_gemm_variant"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B,
-                                         "dtype": "bf16 MFMA operands, fp32 accumulate/storage"}
 
     roofline = None
+    roofline_error = None
     gemm_flops_per_step = None
     if not a.no_roofline:
-        # second pass over the same steps with HIP-event timing armed around every launch of the dominant
-        # kernel family (grouped fp32 MFMA GEMM); kept out of the pass that produces `value`.  EVERY rank runs
-        # the steps (they contain the gradient all-reduce); rank 0 reports its own kernels.
-        from nast_amd import _lib
-        lib = _lib.load()
-        # The two-stream overlap is switched off for this pass: an event pair around a launch measures that
-        # kernel's own duration only while nothing else shares the GPU with it.
-        model.overlap_passes = False
-        lib.nast_prof_begin(0)        # every family: 1 GEMM, 2 vocabulary row kernels, 3 alignment DP
-        run(min(a.steps, 5), offset=a.warmup)
-        torch.cuda.synchronize()
-        model.overlap_passes = not a.no_overlap
-        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-        lib.nast_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
-        if rank == 0 and ms.value > 0:
-            ach = fl.value / (ms.value * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "nast_gemm_f32_kernel (tiled fp32 MFMA GEMM, 78 % of kernel time)",
-                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                        "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
-                        "avg_launch_gflop": round(fl.value / max(n.value, 1) / 1e9, 4)}
-            # the small-M GEMM kernel of the greedy decode (M = sentences, latency-bound) and the family as a whole
-            ms4, fl4, n4 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-            lib.nast_prof_get(4, ctypes.byref(ms4), ctypes.byref(fl4), ctypes.byref(n4))
-            gemm_flops_per_step = (fl.value + fl4.value) / max(min(a.steps, 5), 1)      # GEMM FLOP actually issued per step
-            if ms4.value > 0:
-                roofline["decode_small_m_gemm"] = {"achieved": round(fl4.value / (ms4.value * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
-                                                   "launches": int(n4.value), "avg_launch_us": round(ms4.value * 1e3 / max(n4.value, 1), 2)}
-                allf = (fl.value + fl4.value) / ((ms.value + ms4.value) * 1e-3) / 1e12
-                roofline["gemm_family_all"] = {"achieved": round(allf, 2), "frac": round(allf / PEAK_FP32_MFMA_TFLOPS, 4),
-                                               "launches": int(n.value + n4.value)}
-            # the HBM-bound families next to it: algorithmic bytes (SURVEY.md section 8d) / HIP-event time
-            hbm = {}
-            for kind, name in ((2, "vocab_row_kernels"), (3, "alignment_dp")):
-                lib.nast_prof_get(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
-                if ms.value > 0:
-                    gbs = fl.value / (ms.value * 1e-3) / 1e9
-                    hbm[name] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                 "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2)}
-            roofline["hbm_bound_kernels"] = hbm
-            # HBM-side bytes per launch of the same kernel family from the committed PMC passes (tools/pmc_traffic.py,
-            # profiles/r2_pmc_traffic.txt: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections of the microarchitecture guide)
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
-            if B == 512 and learnable and os.path.exists(tpath):
-                with open(tpath) as f:
-                    t = json.load(f)
-                fams = [t[k] for k in ("nast_gemm_f32_kernel",) if k in t]
-                if fams:
-                    roofline["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
-                    roofline["traffic_unit"] = "bytes per launch, PMC passes recorded in profiles/r2_pmc_traffic.txt"
-                for name, keys in (("vocab_row_kernels", ("nast_log_softmax_fwd_rr_kernel", "nast_softmax_bwd_rr_kernel", "nast_nll_log_softmax_bwd_kernel",
-                                                          "nast_gumbel_softmax_fwd_rr_kernel")),):
-                    fams = [t[k] for k in keys if k in t]
-                    if fams and name in hbm:
-                        hbm[name]["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
+        try:
+            # second pass over the same steps with HIP-event timing armed around every launch of the dominant
+            # kernel family (grouped fp32 MFMA GEMM); kept out of the pass that produces `value`.  EVERY rank runs
+            # the steps (they contain the gradient all-reduce); rank 0 reports its own kernels.
+            from nast_amd import _lib
+            lib = _lib.load()
+            # The two-stream overlap is switched off for this pass: an event pair around a launch measures that
+            # kernel's own duration only while nothing else shares the GPU with it.
+            model.overlap_passes = False
+            lib.nast_prof_begin(0)        # every family: 1 GEMM, 2 vocabulary row kernels, 3 alignment DP
+            run(min(a.steps, 5), offset=a.warmup)
+            torch.cuda.synchronize()
+            model.overlap_passes = not a.no_overlap
+            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+            lib.nast_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+            if rank == 0 and ms.value > 0:
+                ach = fl.value / (ms.value * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "kernel": "nast_gemm_f32_kernel (tiled fp32 MFMA GEMM, 78 % of kernel time)",
+                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                            "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
+                            "avg_launch_gflop": round(fl.value / max(n.value, 1) / 1e9, 4)}
+                # the small-M GEMM kernel of the greedy decode (M = sentences, latency-bound) and the family as a whole
+                ms4, fl4, n4 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+                lib.nast_prof_get(4, ctypes.byref(ms4), ctypes.byref(fl4), ctypes.byref(n4))
+                gemm_flops_per_step = (fl.value + fl4.value) / max(min(a.steps, 5), 1)      # GEMM FLOP actually issued per step
+                if ms4.value > 0:
+                    roofline["decode_small_m_gemm"] = {"achieved": round(fl4.value / (ms4.value * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                                       "launches": int(n4.value), "avg_launch_us": round(ms4.value * 1e3 / max(n4.value, 1), 2)}
+                    allf = (fl.value + fl4.value) / ((ms.value + ms4.value) * 1e-3) / 1e12
+                    roofline["gemm_family_all"] = {"achieved": round(allf, 2), "frac": round(allf / PEAK_FP32_MFMA_TFLOPS, 4),
+                                                   "launches": int(n.value + n4.value)}
+                # the HBM-bound families next to it: algorithmic bytes (SURVEY.md section 8d) / HIP-event time
+                hbm = {}
+                for kind, name in ((2, "vocab_row_kernels"), (3, "alignment_dp")):
+                    lib.nast_prof_get(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+                    if ms.value > 0:
+                        gbs = fl.value / (ms.value * 1e-3) / 1e9
+                        hbm[name] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                     "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2)}
+                roofline["hbm_bound_kernels"] = hbm
+                # HBM-side bytes per launch of the same kernel family from the committed PMC passes (tools/pmc_traffic.py,
+                # profiles/r2_pmc_traffic.txt: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections of the microarchitecture guide)
+                tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
+                if B == 512 and learnable and os.path.exists(tpath):
+                    with open(tpath) as f:
+                        t = json.load(f)
+                    fams = [t[k] for k in ("nast_gemm_f32_kernel",) if k in t]
+                    if fams:
+                        roofline["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
+                        roofline["traffic_unit"] = "bytes per launch, PMC passes recorded in profiles/r2_pmc_traffic.txt"
+                    for name, keys in (("vocab_row_kernels", ("nast_log_softmax_fwd_rr_kernel", "nast_softmax_bwd_rr_kernel", "nast_nll_log_softmax_bwd_kernel",
+                                                              "nast_gumbel_softmax_fwd_rr_kernel")),):
+                        fams = [t[k] for k in keys if k in t]
+                        if fams and name in hbm:
+                            hbm[name]["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
+        except Exception as e:      # noqa: BLE001  (the headline line is printed regardless)
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            roofline_error = f"{type(e).__name__}: {e}"[:300]
+            model.overlap_passes = not a.no_overlap
     if dist_on:
         dist.barrier()
         if debug:
@@ -406,10 +423,17 @@ def main():
             out["step_frac_of_fp32_mfma_peak"] = round(tf / (PEAK_FP32_MFMA_TFLOPS * world), 4)
         if roofline:
             out["roofline"] = roofline
+        elif roofline_error:
+            out["roofline_error"] = roofline_error
         if also:
             out["also"] = also
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, cfg, B)
+            try:
+                out["cpu_baseline"] = cpu_baseline(model, cfg, B)
+            except Exception as e:      # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                out["cpu_baseline_error"] = f"{type(e).__name__}: {e}"[:300]
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist_on:
