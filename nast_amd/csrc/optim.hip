@@ -72,19 +72,42 @@ __global__ __launch_bounds__(256) void nast_multi_adam_kernel(float* const* __re
   const float step = lr / bias_c1;
   const float bc2_sqrt = sqrtf(bias_c2);
   const float w1 = 1.f - beta1, w2 = 1.f - beta2;
-  for (int64_t i = R.lo; i < R.hi; i += R.step) {
-    float gi = g[i];
-    if (total_sq) {
-      gi *= coef;
-      g[i] = gi;                                 // clip_grad_norm_ scales .grad in place
+  auto one = [&](float& gi, float& pi, float& mi, float& vi) {
+    if (total_sq) gi *= coef;                    // clip_grad_norm_ scales .grad in place
+    float ge = gi;
+    if (weight_decay != 0.f) ge += weight_decay * pi;
+    mi = mi + w1 * (ge - mi);
+    vi = vi * beta2 + (w2 * ge) * ge;
+    pi += -step * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  };
+  int64_t lo = R.lo;
+  if (chunk_tensor != nullptr) {
+    // chunk of consecutive elements: 16-byte accesses over its 4-aligned body (same arithmetic per element), scalar tail
+    const int64_t c0 = R.lo - threadIdx.x;
+    const bool al = ((reinterpret_cast<uintptr_t>(g + c0) | reinterpret_cast<uintptr_t>(p + c0) | reinterpret_cast<uintptr_t>(m + c0) |
+                      reinterpret_cast<uintptr_t>(v + c0)) & 15) == 0;
+    if (al) {
+      const int64_t n4 = (R.hi - c0) / 4;
+      for (int64_t q = threadIdx.x; q < n4; q += 256) {
+        const int64_t i = c0 + 4 * q;
+        float4 g4 = *reinterpret_cast<const float4*>(g + i), p4 = *reinterpret_cast<const float4*>(p + i);
+        float4 m4 = *reinterpret_cast<const float4*>(m + i), v4 = *reinterpret_cast<const float4*>(v + i);
+        one(g4.x, p4.x, m4.x, v4.x); one(g4.y, p4.y, m4.y, v4.y); one(g4.z, p4.z, m4.z, v4.z); one(g4.w, p4.w, m4.w, v4.w);
+        if (total_sq) *reinterpret_cast<float4*>(g + i) = g4;
+        *reinterpret_cast<float4*>(m + i) = m4;
+        *reinterpret_cast<float4*>(v + i) = v4;
+        *reinterpret_cast<float4*>(p + i) = p4;
+      }
+      lo = c0 + 4 * n4 + threadIdx.x;
     }
-    if (weight_decay != 0.f) gi += weight_decay * p[i];
-    const float m0 = m[i];
-    const float mi = m0 + w1 * (gi - m0);
-    const float vi = v[i] * beta2 + (w2 * gi) * gi;
+  }
+  for (int64_t i = lo; i < R.hi; i += R.step) {
+    float gi = g[i], pi = p[i], mi = m[i], vi = v[i];
+    one(gi, pi, mi, vi);
+    if (total_sq) g[i] = gi;
     m[i] = mi;
     v[i] = vi;
-    p[i] += -step * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    p[i] = pi;
   }
 }
 
