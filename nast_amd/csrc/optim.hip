@@ -35,8 +35,21 @@ __global__ __launch_bounds__(256) void nast_multi_sqnorm_kernel(const float* con
   const ChunkRange R = chunk_range(chunk_tensor, chunk_off, chunk_elems, sizes);
   const float* g = grads[R.tensor];
   double s = 0.0;                                // fp64 partial sums: the kernel is memory-bound, the adds are free
-  if (g)
-    for (int64_t i = R.lo; i < R.hi; i += R.step) s += (double)g[i] * (double)g[i];
+  if (g) {
+    int64_t lo = R.lo;
+    if (chunk_tensor != nullptr) {               // 16-byte loads over the chunk's 4-aligned body, scalar tail
+      const int64_t c0 = R.lo - threadIdx.x;
+      if ((reinterpret_cast<uintptr_t>(g + c0) & 15) == 0) {
+        const int64_t n4 = (R.hi - c0) / 4;
+        for (int64_t q = threadIdx.x; q < n4; q += 256) {
+          const float4 x = *reinterpret_cast<const float4*>(g + c0 + 4 * q);
+          s += (double)x.x * (double)x.x + (double)x.y * (double)x.y + (double)x.z * (double)x.z + (double)x.w * (double)x.w;
+        }
+        lo = c0 + 4 * n4 + threadIdx.x;
+      }
+    }
+    for (int64_t i = lo; i < R.hi; i += R.step) s += (double)g[i] * (double)g[i];
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
