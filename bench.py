@@ -126,6 +126,73 @@ def cpu_baseline(model, cfg, B, steps=5, warm=2):
                       f"{threads} threads"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh child processes (one rank per GPU, the
+    environment torch.distributed.run would give them), relay rank 0's one JSON line, and fail loudly -- exit code 1 and
+    the failing rank's stderr tail -- if a rank dies or the job exceeds its deadline.  Nothing here touches the GPU: the
+    children are started before this process has made any HIP call (never an exec from a process that has)."""
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    deadline = time.time() + float(os.environ.get("NAST_BENCH_TIMEOUT_S", "1500"))
+    logs, procs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or n) // n))))
+        log = tempfile.TemporaryFile(mode="w+b")
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdin=subprocess.DEVNULL,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=log))
+
+    def tail(r, nbytes=4000):
+        logs[r].seek(0, os.SEEK_END)
+        size = logs[r].tell()
+        logs[r].seek(max(0, size - nbytes))
+        return logs[r].read().decode(errors="replace")
+
+    failed = None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = (bad[0], f"rank {bad[0]} exited with code {codes[bad[0]]}")
+        elif all(c == 0 for c in codes):
+            break
+        elif time.time() > deadline:
+            slow = [r for r, c in enumerate(codes) if c is None]
+            failed = (slow[0], f"rank(s) {slow} still running at the deadline (NAST_BENCH_TIMEOUT_S)")
+        else:
+            time.sleep(0.2)
+    if failed is not None:
+        for p in procs:                       # the exact children started above, nothing else
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        r, why = failed
+        sys.stderr.write(f"[bench] {why}; stderr tail of rank {r}:\n{tail(r)}\n")
+        for q in range(n):
+            if q != r:
+                sys.stderr.write(f"[bench] --- rank {q} (last lines) ---\n{tail(q, 800)}\n")
+        sys.exit(1)
+    out = procs[0].stdout.read().decode()
+    for r in range(n):
+        sys.stderr.write(tail(r, 2000))
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        sys.stderr.write(f"[bench] expected one JSON line from rank 0, got {len(lines)}\n")
+        sys.exit(1)
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+
+
 def main():
     # stdout carries ONE JSON line: everything else that writes to file descriptor 1 (RCCL prints its version banner there under
     # NCCL_DEBUG=VERSION, which the GPU boxes set) is sent to stderr; the line itself goes to the saved descriptor
@@ -147,10 +214,14 @@ def main():
                     help="GEMM arithmetic: fp32 MFMA (reference dtype, default) or the bf16-MFMA variant")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.dup2(real_stdout, 1)
+        return launch_ranks(a.gpus, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
     # NAST_DIST_BACKEND=gloo is a rehearsal aid: several ranks may then share one GPU (RCCL needs one GPU per rank)
     backend = os.environ.get("NAST_DIST_BACKEND", "nccl")
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank

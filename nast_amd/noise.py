@@ -46,8 +46,23 @@ class NoiseLayer(nn.Module):
         out = []
         for tf in freq:
             p = tf * idf
-            out.append(p / p.sum())
-        return np.array(out)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                out.append(p / p.sum())          # a style without tf-idf mass gives NaN here as in the reference (noise.py:52-56);
+        return np.array(out)                     # _checked_cnt() refuses to draw from such a row
+
+    def _checked_cnt(self):
+        """`cnt` for word_add, validated once per content version: torch.multinomial on a NaN / zero-mass row is undefined
+        behaviour on the device (the reference would draw from it silently)."""
+        ver = (self.cnt._version, self.cnt.data_ptr())
+        if getattr(self, "_cnt_ok", None) != ver:
+            c = self.cnt
+            bad = ~(torch.isfinite(c).all(1) & (c >= 0).all(1) & (c.sum(1) > 0))
+            if bool(bad.any()):
+                raise ValueError(f"NoiseLayer.word_add: the word distribution of style(s) {bad.nonzero().flatten().tolist()} has no "
+                                 "tf-idf mass (every word of that style occurs in > 30 % of the sentences, or the style is empty): "
+                                 "set word_add = 0 or provide NoiseLayer.cnt")
+            self._cnt_ok = ver
+        return self.cnt
 
     # ---- stages as pure functions of their random draws ------------------------------------
     def blank_apply(self, x, l, u):
@@ -138,7 +153,7 @@ class NoiseLayer(nn.Module):
             kw.update(u_blank=torch.rand(S, B, dtype=torch.float64, device=dev), blank_prob=self.blank_prob)
         if self.add_prob != 0:
             assert self.add_prob < 1
-            dist = self.cnt[rev_domain.to(self.cnt.device)].to(dev)
+            dist = self._checked_cnt()[rev_domain.to(self.cnt.device)].to(dev)
             kw.update(u_add=torch.rand(M - 1, B, dtype=torch.float64, device=dev), add_prob=self.add_prob,
                       new_words=torch.multinomial(dist, M, True).transpose(0, 1).contiguous())
         if self.dropout_prob != 0 or self.repeat_prob != 0:
@@ -178,7 +193,7 @@ class NoiseLayer(nn.Module):
         if self.add_prob != 0:
             assert self.add_prob < 1
             u = np.random.rand(M - 1, x.shape[1])
-            dist = self.cnt[rev_domain.to(self.cnt.device)]
+            dist = self._checked_cnt()[rev_domain.to(self.cnt.device)]
             new_words = torch.multinomial(dist, M, True).transpose(0, 1).cpu().numpy()
             x, l = self.add_apply(x, l, u, new_words)
         if self.dropout_prob != 0 or self.repeat_prob != 0:

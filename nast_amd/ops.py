@@ -166,8 +166,13 @@ def zeros_like_many(tensors):
 # (seq2seq.py:464, :530) and no index_put through a [V, d] temporary for single embedding rows.
 # `grad_listener` (set by nast_amd.ddp.GradReducer) is told about every in-place contribution, because
 # autograd's post-accumulate hooks do not fire for gradients that never pass through AccumulateGrad.
+# `sink_hook` (same owner) is asked BEFORE an in-place kernel is enqueued and may hand out another buffer to add into (a
+# parameter whose gradient bucket is already being all-reduced).  Every parameter that is handed a sink is marked
+# `_nast_touched`: nast_amd.optim.FusedAdam steps only the parameters that took part since its zero_grad(), as
+# torch.optim.Adam skips `grad is None` -- the persistent, zero-filled buffers used here would otherwise be stepped.
 INPLACE_GRADS = True
 grad_listener = None
+sink_hook = None
 # Streams whose backward nodes add into the same .grad buffers (nast_amd.seq2seq: main + second stream).  A buffer that
 # is created lazily is zero-filled on ONE of them; the others must not start adding before that fill has run.
 peer_streams = ()
@@ -176,6 +181,11 @@ peer_streams = ()
 def _sink(p):
     if not INPLACE_GRADS or p is None or not p.is_leaf:
         return None
+    p._nast_touched = True
+    if sink_hook is not None:
+        other = sink_hook(p)
+        if other is not None:
+            return other
     if p.grad is None:
         p.grad = torch.zeros_like(p)
         if p.is_cuda and peer_streams:

@@ -27,6 +27,31 @@ class FusedAdam(optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._tables = {}
         self._dev_step = None       # float64 [1] on the device: the common step count, kept for HIP-graph replays
+        self._track = False
+        self.grad_arena = None      # nast_amd.ddp.GradReducer whose flat buffer holds this optimizer's .grad slices
+
+    # -- participation ---------------------------------------------------------------------------
+    def track_participation(self):
+        """Step only the parameters that received a gradient contribution since the last zero_grad().  torch.optim.Adam
+        skips `grad is None` (what zero_grad() leaves behind in the reference, seq2seq.py:435); here the gradient buffers
+        persist zero-filled (the HIP kernels accumulate in place, data parallelism keeps them in one flat buffer), so the
+        contributions themselves are tracked: nast_amd.ops marks every parameter it hands a gradient sink, a
+        post-accumulate hook marks the ones autograd writes.  Without this a parameter that sits out a step (the length
+        predictor while `use_inference_z=False`, sos_token under data parallelism) would advance its step count, keep
+        moving on its momentum and take weight decay."""
+        if self._track:
+            return
+        self._track = True
+
+        def mark(p):
+            p._nast_touched = True
+        for g in self.param_groups:
+            for p in g["params"]:
+                p._nast_touched = False
+                p.register_post_accumulate_grad_hook(mark)
+
+    def _takes_part(self, p):
+        return p.grad is not None and (not self._track or getattr(p, "_nast_touched", False))
 
     # -- step count on the device (nast_amd/graph.py) ------------------------------------------
     def device_step_counter(self):
@@ -51,8 +76,14 @@ class FusedAdam(optim.Adam):
     def zero_grad(self, set_to_none=True):
         """set_to_none=False (what the in-place gradient kernels need) zeroes every buffer in a few multi-tensor launches
         instead of one fill per parameter (263 launches per step for the generator group)."""
+        if self._track:
+            for g in self.param_groups:
+                for p in g["params"]:
+                    p._nast_touched = False
         if set_to_none:
             return super().zero_grad(set_to_none=True)
+        if self.grad_arena is not None and self.grad_arena.arena is not None:
+            return self.grad_arena.zero_grads()              # the slices of one flat buffer: one fill
         grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
         for gr in grads:
             if gr.grad_fn is not None or gr.requires_grad:
@@ -86,18 +117,28 @@ class FusedAdam(optim.Adam):
         total gradient norm as a 0-d device tensor (None without clipping).
         capturing=True (under HIP-graph capture): the bias corrections come from the device step counter, which the
         captured work increments; the host-side counts are left to note_replayed_step()."""
-        plists = [[p for p in g["params"] if p.grad is not None] for g in self.param_groups]
+        plists = [[p for p in g["params"] if self._takes_part(p)] for g in self.param_groups]
         flat = [p for pl in plists for p in pl]
         if not flat:
             return None
         if not flat[0].is_cuda:
             norm = clip_grad_norm_(flat, max_norm) if max_norm is not None else None
-            super().step()
+            idle = [(p, p.grad) for g in self.param_groups for p in g["params"] if p.grad is not None and not self._takes_part(p)]
+            for p, _ in idle:                               # torch's own step: hide the gradients of those that sat out
+                p.grad = None
+            try:
+                super().step()
+            finally:
+                for p, gr in idle:
+                    p.grad = gr
             return norm
         for p in flat:
             if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous() or p.grad.is_sparse:
                 raise NotImplementedError("FusedAdam: contiguous dense fp32 parameters and gradients only")
             st = self.state[p]
+            if len(st) and st["exp_avg"].device != p.device:
+                raise RuntimeError(f"FusedAdam: optimizer state on {st['exp_avg'].device} but the parameter on {p.device} "
+                                   "(load_state_dict before the model was moved?): move the state with the parameters")
             if len(st) == 0:
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)

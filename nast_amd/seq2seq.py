@@ -62,6 +62,9 @@ class Seq2seq(BaseModel):
         super().__init__(param, net, {"optimizer_F": self.optimizer_F, "optimizer_D": self.optimizer_D})
         self.reducer_F = GradReducer(list(self.net.model_F.parameters()))
         self.reducer_D = GradReducer(list(self.net.model_D.parameters()))
+        for opt, red in ((self.optimizer_F, self.reducer_F), (self.optimizer_D, self.reducer_D)):
+            opt.track_participation()          # a parameter that sits out a step is skipped, as Adam skips `grad is None`
+            opt.grad_arena = red if red.enabled else None
 
     overlap_passes = True      # f_step: run the transfer pass on a second stream beside pass 1 (set False to serialise)
     _streams = None

@@ -17,8 +17,12 @@ class BaseModel:
         self.checkpoint_manager = checkpoint_manager
         if args.cuda is True:
             raise RuntimeError("Please use cuda or cpu for args.cuda")
-        if args.get("restore") is not None:
+        restored = args.get("restore") is not None
+        if restored:
             self.restore(args.restore)                       # model_helper.py:53-88
+            cb = param.volatile.get("restoreCallback")
+            if cb:
+                cb(self)                                     # model_helper.py:98-99
         self.net = self.net.to(args.cuda)
 
     def restore(self, path):
@@ -31,8 +35,11 @@ class BaseModel:
             raise NotImplementedError(f"args.restore={path!r}: only a checkpoint file path is supported on this path "
                                       "(the checkpoint manager's names and URLs are out of scope, SURVEY 2.1 row 11)")
         ck = torch.load(path, map_location="cpu", weights_only=True)
+        if self.args.get("restore_other_weights"):
+            raise NotImplementedError("args.restore_other_weights: annealed hyper-parameters (other_weights) are out of scope "
+                                      "(SURVEY 2.1 row 11)")
         self.now_batch, self.now_epoch = ck["now_batch"], ck["now_epoch"]
-        self.net.load_state_dict(ck["weights"])
+        self.net.load_state_dict(ck["weights"], self.param.volatile.get("load_exclude_set"))             # model_helper.py:65 (excluded keys keep their init)
         if self.args.get("restore_optimizer", True):
             for name, opt in self.optimizerList.items():
                 if name in ck and ck[name].get("state"):
@@ -40,7 +47,17 @@ class BaseModel:
                     opt.load_state_dict(ck[name])
                     for g, new in zip(opt.param_groups, keep):        # the run's own hyper-parameters win (:70-77)
                         g.update(new)
+                    self.optimizerCuda(opt)
         return ck
+
+    def optimizerCuda(self, optimizer):
+        """model_helper.py:135-139: load_state_dict casts the moments to the parameters' device AT THAT MOMENT -- the host,
+        since the network moves to args.cuda only afterwards and `.to()` moves parameter data, not optimizer state.  The step
+        counts stay host scalars (torch.optim.Adam's layout; FusedAdam reads them on the host)."""
+        for state in optimizer.state.values():
+            for k, v in state.items():
+                if torch.is_tensor(v) and k != "step":
+                    state[k] = v.to(self.args.cuda)
 
     def zero_grad(self):
         for p in self.net.parameters():

@@ -220,8 +220,14 @@ ref.load_state_dict(net.state_dict())
 unused = torch.nn.Parameter(torch.zeros(3))                      # like sos_token: never gets a gradient
 w2 = torch.nn.Parameter(torch.rand(4) + 0.5)                     # gradient written IN PLACE, twice per backward
 w2_ref = torch.nn.Parameter(w2.detach().clone())
-params = list(net.parameters()) + [unused, w2]
+late = torch.nn.Parameter(torch.rand(4) + 0.5)                   # first takes part in the last step (like the length predictor)
+late_ref = torch.nn.Parameter(late.detach().clone())
+params = list(net.parameters()) + [unused, w2, late]
 red = GradReducer(params, bucket_bytes=4096)
+assert red.arena is not None and red.n_buckets > 1
+assert all(p.grad is not None and p.grad.data_ptr() == s.data_ptr() for p, s in zip(red.params, red._slices))
+# layout: reverse registration order, buckets are contiguous ranges of the flat buffer
+assert red.bucket_of[len(params) - 1] == 0 and red.ranges[0][0] == 0 and red.ranges[-1][1] == red.arena.numel()
 
 
 class InPlaceScale(torch.autograd.Function):                    # the pattern of the HIP backward kernels
@@ -235,10 +241,9 @@ class InPlaceScale(torch.autograd.Function):                    # the pattern of
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         w = ctx.w
-        if w.grad is None:
-            w.grad = torch.zeros_like(w)
-        w.grad += (g * x).sum(0)
-        ops.grad_listener(w)
+        (buf,), _ = ops.grad_buffers([w])       # the parameter's .grad, or a side buffer when its bucket has left
+        buf += (g * x).sum(0)
+        ops.grads_written([w])
         return g * w.detach(), None
 
 
@@ -249,12 +254,18 @@ def fwd(m, X, w, inplace):
     return (y * w).tanh() * w
 
 
+def check(pairs, what):
+    for p, q in pairs:
+        assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), (what, (p.grad - q.grad).abs().max())
+
+
+pairs = list(zip(list(net.parameters()) + [w2], list(ref.parameters()) + [w2_ref]))
 g = torch.Generator().manual_seed(5)
 for step in range(4):
     X = torch.randn(2 * world * 4, 16, generator=g); Y = torch.randn(2 * world * 4, 4, generator=g)
     Xa, Ya = X[: world * 4], Y[: world * 4]; Xb, Yb = X[world * 4:], Y[world * 4:]
     sl = slice(rank * 4, rank * 4 + 4)
-    for p in params: p.grad = None
+    red.zero_grads()
     # two backward passes accumulating into the same grads; only the second is reduced (f_step pattern)
     ((fwd(net, Xa[sl], w2, True) - Ya[sl]) ** 2).sum().div(4).backward()
     red.arm("two-pass")
@@ -262,21 +273,32 @@ for step in range(4):
     red.finish()
     for p in list(ref.parameters()) + [w2_ref]: p.grad = None
     (((fwd(ref, Xa, w2_ref, False) - Ya) ** 2).sum() / (4 * world) + ((fwd(ref, Xb, w2_ref, False) - Yb) ** 2).sum() / (4 * world)).backward()
-    for p, q in zip(list(net.parameters()) + [w2], list(ref.parameters()) + [w2_ref]):
-        assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), (step, (p.grad - q.grad).abs().max())
-    assert unused.grad is None
-    assert len(red.plan.buckets) > 1 and red.plan.counts[red.index[id(w2)]] >= 2
-# a step whose graph has MORE in-place contributions than the learnt plan must still be exact (fallback path)
-for p in params: p.grad = None
+    check(pairs, step)
+    plan = red.plans["two-pass"]
+    iu, il = red.index[id(unused)], red.index[id(late)]
+    assert iu not in plan.part and il not in plan.part and float(unused.grad.abs().sum()) == 0
+    assert plan.counts[red.index[id(w2)]] >= 2
+assert red.stats["learnt"] == 1 and red.stats["overlapped" if red.overlap else "after_backward"] == 3, red.stats
+# a step whose graph has MORE in-place contributions than the learnt plan, and a parameter that takes part for the first
+# time, must still be exact (side buffers, reduced on their own)
+red.zero_grads()
 X = torch.randn(world * 4, 16, generator=g); Y = torch.randn(world * 4, 4, generator=g)
 sl = slice(rank * 4, rank * 4 + 4)
 red.arm("two-pass")
-((InPlaceScale.apply(fwd(net, X[sl], w2, True), w2) - Y[sl]) ** 2).sum().div(4).backward()
+((InPlaceScale.apply(InPlaceScale.apply(fwd(net, X[sl], w2, True), w2), late) - Y[sl]) ** 2).sum().div(4).backward()
 red.finish()
-for p in list(ref.parameters()) + [w2_ref]: p.grad = None
-(((fwd(ref, X, w2_ref, False) * w2_ref - Y) ** 2).sum() / (4 * world)).backward()
-for p, q in zip(list(net.parameters()) + [w2], list(ref.parameters()) + [w2_ref]):
-    assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), ("changed graph", (p.grad - q.grad).abs().max())
+for p in list(ref.parameters()) + [w2_ref, late_ref]: p.grad = None
+(((fwd(ref, X, w2_ref, False) * w2_ref * late_ref - Y) ** 2).sum() / (4 * world)).backward()
+check(pairs + [(late, late_ref)], "changed graph")
+assert red.stats["late"] == 1 and red.index[id(late)] in red.plans["two-pass"].part, red.stats
+# ... and the re-learnt plan covers that graph from now on
+red.zero_grads()
+red.arm("two-pass")
+((InPlaceScale.apply(InPlaceScale.apply(fwd(net, X[sl], w2, True), w2), late) - Y[sl]) ** 2).sum().div(4).backward()
+red.finish()
+check(pairs + [(late, late_ref)], "re-learnt graph")
+assert red.stats["late"] == 1, red.stats
+red._verify_previous(block=True)
 dist.destroy_process_group()
 print("ok", rank)
 '''
@@ -372,3 +394,13 @@ def test_restore_from_checkpoint_file(tmp_path):
     pc.args.restore = "last"
     with pytest.raises(NotImplementedError):
         Seq2seq(pc)
+
+
+def test_fused_adam_participation_host_path():
+    """The same bookkeeping on the host path (CPU parameters take torch's own Adam step): see
+    test_kernels_gpu.py::test_fused_adam_skips_parameters_that_sat_out for the device kernels."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_tk", os.path.join(ROOT, "tests", "test_kernels_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod._participation_case("cpu")

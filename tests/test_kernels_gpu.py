@@ -485,6 +485,49 @@ def test_fused_adam_late_first_gradient(ops):
     assert {float(st["step"]) for st in o_got.state_dict()["state"].values()} == {6.0, 3.0, 5.0}
 
 
+def _participation_case(device):
+    """FusedAdam.track_participation(): persistent zero-filled .grad buffers (zero_grad(set_to_none=False), the data-parallel
+    flat buffer) against torch.optim.Adam with zero_grad() -> None.  Tensor 2 sits out steps 0-1 AND step 4 (the length
+    predictor around `pre_z_batch`, seq2seq.py:241-247), tensor 3 never takes part (sos_token); weight decay on: a parameter
+    that sits out must not decay, move on its momentum or advance its step count."""
+    from nast_amd import ops as O
+    from nast_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(21)
+    shapes = [(300, 64), (64,), (128, 32), (5,)]
+    ref = [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
+    got = [t.detach().clone().to(device).requires_grad_(True) for t in ref]
+    o_ref, o_got = torch.optim.Adam(ref, lr=1e-3, weight_decay=1e-2), FusedAdam(got, lr=1e-3, weight_decay=1e-2)
+    o_got.track_participation()
+    for b in got:
+        b.grad = torch.zeros_like(b)              # buffers exist from the start and are never None again
+    for step in range(6):
+        o_ref.zero_grad()
+        o_got.zero_grad(set_to_none=False)
+        for i, (a, b) in enumerate(zip(ref, got)):
+            if i == 3 or (i == 2 and step in (0, 1, 4)):
+                continue
+            gr = torch.randn(a.shape, generator=g)
+            a.grad = gr.clone()
+            if i == 0:                            # through autograd's AccumulateGrad (post-accumulate hook) ...
+                (b * gr.to(device)).sum().backward()
+            else:                                 # ... or in place through the kernels' gradient sink
+                (buf,), _ = O.grad_buffers([b])
+                assert buf.data_ptr() == b.grad.data_ptr()
+                buf += gr.to(device)
+        torch.nn.utils.clip_grad_norm_([p for p in ref if p.grad is not None], 5.0)
+        o_ref.step()
+        o_got.clip_and_step(5.0)
+        for a, b in zip(ref, got):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().numpy(), rtol=1e-5, atol=2e-7, err_msg=f"step {step}")
+    sd_ref, sd_got = o_ref.state_dict()["state"], o_got.state_dict()["state"]
+    assert sd_ref.keys() == sd_got.keys() == {0, 1, 2}
+    assert [float(sd_got[k]["step"]) for k in (0, 1, 2)] == [float(sd_ref[k]["step"]) for k in (0, 1, 2)] == [6.0, 6.0, 3.0]
+
+
+def test_fused_adam_skips_parameters_that_sat_out(ops):
+    _participation_case("cuda")
+
+
 @pytest.mark.parametrize("max_norm,wd", [(5.0, 0.0), (0.05, 0.0), (None, 0.0), (5.0, 1e-3)])
 def test_fused_adam_matches_torch(ops, max_norm, wd):
     """FusedAdam.clip_and_step == clip_grad_norm_ + torch.optim.Adam.step over several steps (seq2seq.py:536-537),
