@@ -466,6 +466,9 @@ def main():
             model.overlap_passes = not a.no_overlap
     if dist_on:
         dist.barrier()
+        import nast_amd.ddp as _ddp
+        if _ddp.PROF:
+            print(f"[rank {rank}] reducer host profile (calls, seconds) {_ddp.prof} stats {model.reducer_F.stats}", file=sys.stderr, flush=True)
         if debug:
             print(f"[rank {rank}] reducer F {model.reducer_F.stats} arena {model.reducer_F.arena is not None} buckets "
                   f"{ {k: [len(b) for b in p.buckets] for k, p in model.reducer_F.plans.items()} }", file=sys.stderr, flush=True)

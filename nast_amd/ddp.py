@@ -30,8 +30,9 @@ the stream wait for the collectives: stream-ordered, no host synchronisation on 
     already been added to a buffer in flight: that raises.)
   * Every rank checks, one step late and without a host wait, that its peers ran the same plan (a 3-word all-reduce whose
     result is copied to pinned memory); a mismatch raises instead of mixing gradients.
-  * `NAST_DDP_OVERLAP=0` (default for any other backend): all buckets leave from `finish()`, after backward.  With gloo on
-    device buffers the device is drained first (`NAST_DDP_SYNC`, see DESIGN.md section 6 for why).
+  * `NAST_DDP_OVERLAP=0` (default for any other backend): all buckets leave from `finish()`, after backward.  With gloo and
+    device gradients (rehearsals: several ranks sharing one GPU) each bucket is staged through pinned host memory by this
+    module with blocking copies; gloo never sees a device buffer (DESIGN.md section 6 for why).
   * Host-blocking waits (gloo) have a deadline (`NAST_DDP_TIMEOUT_S`, default 120 s) and fail with rank, bucket and step
     variant in the message; on RCCL the process group's watchdog (same timeout, bench.py passes it) plays that role.
 
@@ -66,6 +67,28 @@ def _sink_hook(p):
     return None
 
 
+PROF = os.environ.get("NAST_DDP_PROF") == "1"      # host seconds and calls per entry point, printed by bench.py's debug line
+prof = {}
+
+
+def _timed(fn):
+    if not PROF:
+        return fn
+    import functools
+    import time
+
+    @functools.wraps(fn)
+    def wrap(*a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            e = prof.setdefault(fn.__name__, [0, 0.0])
+            e[0] += 1
+            e[1] += time.perf_counter() - t
+    return wrap
+
+
 class _Plan:
     """What one step variant does to the arena: contributions per parameter in the armed backward, and who takes part."""
 
@@ -85,8 +108,6 @@ class GradReducer:
     BUCKET_BYTES = int(float(os.environ["NAST_DDP_BUCKET_MB"]) * (1 << 20)) if "NAST_DDP_BUCKET_MB" in os.environ else (16 << 20)
     # launch buckets during backward: None = by backend (RCCL yes, anything else no)
     OVERLAP = {"1": True, "0": False}.get(os.environ.get("NAST_DDP_OVERLAP"))
-    # gloo on device buffers, after-backward mode: drain the device before the collectives are issued
-    SYNC_BEFORE = os.environ.get("NAST_DDP_SYNC", "1") == "1"
     CHECK = os.environ.get("NAST_DDP_CHECK", "1") == "1"
 
     def __init__(self, params, bucket_bytes=None, group=None):
@@ -121,6 +142,8 @@ class GradReducer:
         self._op = dist.ReduceOp.AVG if self.nccl else dist.ReduceOp.SUM
         self._scale = 1.0 if self.nccl else 1.0 / self.world
         self._make_arena()
+        self._staged = self.arena.is_cuda and not self.nccl
+        self._host = None
         from . import ops
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -176,6 +199,7 @@ class GradReducer:
         if i is not None:
             self._notify(i)
 
+    @_timed
     def _sink_param(self, p):
         """Called by ops before an in-place gradient kernel is enqueued: the buffer it must add into when that is not the
         parameter's arena slice (its bucket is already on the wire), else None."""
@@ -192,6 +216,7 @@ class GradReducer:
             return self._late[i]
         return None
 
+    @_timed
     def _notify(self, i):
         if not self.armed:
             return
@@ -213,6 +238,7 @@ class GradReducer:
             self._next += 1
 
     # ---- the step's protocol ------------------------------------------------------------------
+    @_timed
     def arm(self, tag="default", streams=()):
         """Call right before the backward pass whose gradients are final for this step.  `streams`: every HIP stream that
         backward's kernels run on, when more than one (a bucket waits for all of them before it leaves)."""
@@ -237,6 +263,7 @@ class GradReducer:
         if self.plan is not None and self.overlap:
             self._advance()                                     # buckets that backward #1 alone filled leave now
 
+    @_timed
     def _launch(self, b):
         if self.arena.is_cuda:
             # the last contribution may come from a node on one stream while earlier ones are still queued on another
@@ -244,7 +271,16 @@ class GradReducer:
             for st in self._streams:
                 if st != cur:
                     cur.wait_stream(st)
-        self._work[b] = dist.all_reduce(self._views[b], op=self._op, group=self.group, async_op=True)
+        buf = self._views[b]
+        if self._staged:
+            # rehearsal backends (gloo) with device gradients: staged through pinned host memory HERE, with plain blocking
+            # copies, instead of handing gloo the device buffer (ProcessGroupGloo's own device path stops
+            # completing on this image from its second round on, with or without this library in the process)
+            if self._host is None:
+                self._host = [torch.empty(hi - lo, dtype=self.arena.dtype, pin_memory=True) for lo, hi in self.ranges]
+            buf = self._host[b]
+            buf.copy_(self._views[b])
+        self._work[b] = dist.all_reduce(buf, op=self._op, group=self.group, async_op=True)
         self._launched[b] = True
 
     def _wait(self, work, what):
@@ -280,15 +316,19 @@ class GradReducer:
             raise RuntimeError(f"[nast_amd.ddp] rank {dist.get_rank(self.group)}: the ranks ran different gradient exchanges in step "
                                f"variant '{tag}' (state {mine} here, {-ncmin}..{cmax} across ranks): their backward graphs differ")
 
+    @_timed
     def _exchange_state(self, state):
         if not self.CHECK:
             return
         self._verify_previous(block=True)                       # at most one in flight
-        t = torch.empty(2, device=self.arena.device)            # (filled by kernels: a host tensor would cost a blocking copy)
-        t[0].fill_(float(state))
-        t[1].fill_(-float(state))
+        if self.nccl:
+            t = torch.empty(2, device=self.arena.device)        # (filled by kernels: a host tensor would cost a blocking copy)
+            t[0].fill_(float(state))
+            t[1].fill_(-float(state))
+        else:
+            t = torch.tensor([float(state), -float(state)])
         w = dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
-        if self.arena.is_cuda and self.nccl:
+        if self.nccl:
             w.wait()
             if self._pinned is None:
                 self._pinned = torch.empty(2, pin_memory=True)
@@ -299,9 +339,10 @@ class GradReducer:
             self._check = (ev, host, float(state), self.tag)
         else:
             self._wait(w, "state exchange")
-            self._check = (None, t.cpu(), float(state), self.tag)
+            self._check = (None, t, float(state), self.tag)
             self._verify_previous()
 
+    @_timed
     def finish(self):
         """Call after that backward: issues what is left, makes the stream (or, without RCCL, the host) wait for the
         collectives; afterwards every participating .grad holds the average over ranks."""
@@ -316,10 +357,6 @@ class GradReducer:
             for i in self._fired:
                 counts[i] = counts.get(i, 0) + 1
             plan = _Plan(counts, set(self.touched), self.bucket_of, self.n_buckets)
-        if self.arena.is_cuda and not self.nccl and self.SYNC_BEFORE and not self.overlap:
-            for st in self._streams:
-                torch.cuda.current_stream().wait_stream(st)
-            torch.cuda.synchronize()
         for b in range(self._next, self.n_buckets):             # (every bucket, in the learning step and without overlap)
             if plan.send[b] and not self._launched[b]:
                 self._launch(b)
@@ -332,6 +369,8 @@ class GradReducer:
         for b, w in enumerate(self._work):
             if w is not None:
                 self._wait(w, f"bucket {b}")
+                if self._staged:
+                    self._views[b].copy_(self._host[b])
         if self._scale != 1.0:
             lo = None
             for b in range(self.n_buckets + 1):                 # one scaling kernel per run of consecutive sent buckets
@@ -343,8 +382,9 @@ class GradReducer:
                     lo = None
         # contributions that came after their bucket had left: reduced on their own, added to the slice
         for i in sorted(self._late):
-            self._wait(dist.all_reduce(self._late[i], op=self._op, group=self.group, async_op=True), f"late gradient #{i}")
-            self._slices[i].add_(self._late[i], alpha=self._scale)
+            buf = self._late[i].cpu() if self._staged else self._late[i]
+            self._wait(dist.all_reduce(buf, op=self._op, group=self.group, async_op=True), f"late gradient #{i}")
+            self._slices[i].add_(buf.to(self.arena.device), alpha=self._scale)
         unplanned = bool(self._late) or bool(stray)
         if learn:
             self.plans[self.tag] = plan

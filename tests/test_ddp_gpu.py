@@ -40,6 +40,15 @@ if sys.argv[2].endswith("2streams"):
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cfg = dict(V=48, d=32, h=4, N=2, L=8, learnable=learnable, gen_approx_mode="soft", dis_approx_mode="soft")
+prez = "prez" in sys.argv[2]
+if prez:
+    # Steps with use_inference_z=False (`--pre_z_batch`, run.py:61, seq2seq.py:241-247; usable in the reference only with
+    # cyc_rec_enable=False: its generate branch returns a 2-tuple there, transformer.py:78, :521-522): the length predictor
+    # sits out -- before it ever had a gradient (step 0) and after it has Adam state (step 2).  With weight decay on, a parameter that
+    # sits out must neither decay nor move on its momentum nor advance its step count, under data parallelism as alone.
+    cfg["L2"] = 1e-2
+use_z = [False, True, False, True] if prez else [True, True, True]
+n_f = len(use_z) - 1
 U.cuda_init(0, "cuda")
 
 
@@ -64,7 +73,7 @@ def incoming(sent, slen, dom):
 dp = build()                      # reducers are live: the process group exists
 rng = np.random.default_rng(3)
 B = 4 * world
-for step in range(3):
+for step in range(len(use_z)):
     sent, slen = synth_batch(rng, B, cfg["L"], cfg["V"])
     dom = torch.tensor(([0, 0, 1, 1]) * world)
     sl = slice(4 * rank, 4 * rank + 4)
@@ -72,10 +81,10 @@ for step in range(3):
     ident = lambda w, l, rev_domain: (w, l)
     dp.net.noiseLayer.forward = ident
     # approx mode "soft" (seq2seq.py:409): no Gumbel draw, so shards and the full batch see the same soft tokens
-    if step < 2:
-        out = dp.f_step(incoming(sent[sl], slen[sl], dom[sl]), 1.0, use_inference_z=True)
+    if step < n_f:
+        out = dp.f_step(incoming(sent[sl], slen[sl], dom[sl]), 1.0, cyc_rec_enable=use_z[step], use_inference_z=use_z[step])
     else:
-        out = dp.d_step(incoming(sent[sl], slen[sl], dom[sl]), 1.0, use_inference_z=True)
+        out = dp.d_step(incoming(sent[sl], slen[sl], dom[sl]), 1.0, use_inference_z=use_z[step])
     if rank == 0:
         # reference: same weights before the step, whole batch, no process group involvement
         if step == 0:
@@ -85,16 +94,28 @@ for step in range(3):
             ddp_mod.ENABLED = True
             ref.net.noiseLayer.forward = ident
         # (ref was built from the same seed, so it tracks dp step by step)
-        if step < 2:
-            ref.f_step(incoming(sent, slen, dom), 1.0, use_inference_z=True)
+        if step < n_f:
+            ref.f_step(incoming(sent, slen, dom), 1.0, cyc_rec_enable=use_z[step], use_inference_z=use_z[step])
         else:
-            ref.d_step(incoming(sent, slen, dom), 1.0, use_inference_z=True)
+            ref.d_step(incoming(sent, slen, dom), 1.0, use_inference_z=use_z[step])
         # compare the (averaged, clipped) gradients the optimiser consumed.  Weights are not compared directly: Adam turns
         # the rounding noise of analytically-zero gradients (key biases: softmax is shift invariant) into +-lr updates.
-        group = "model_F." if step < 2 else "model_D."
+        group = "model_F." if step < n_f else "model_D."
         pairs = [(n, p.grad, q.grad) for (n, p), (_, q) in zip(dp.net.named_parameters(), ref.net.named_parameters())
-                 if n.startswith(group) and q.grad is not None]
+                 if n.startswith(group) and q.grad is not None and getattr(q, "_nast_touched", True)]
         assert len(pairs) > 20 and all(g is not None for _, g, _ in pairs)
+        # the same parameters were stepped, equally often, on both sides (sos_token never; the length predictor only in
+        # use_inference_z=True steps)
+        opt_dp, opt_ref = (dp.optimizer_F, ref.optimizer_F) if step < n_f else (dp.optimizer_D, ref.optimizer_D)
+        for (n, p), (_, q) in zip(dp.net.named_parameters(), ref.net.named_parameters()):
+            if n.startswith(group):
+                a, b = opt_dp.state.get(p, {}), opt_ref.state.get(q, {})
+                assert float(a.get("step", 0)) == float(b.get("step", 0)), (step, n, a.get("step"), b.get("step"))
+        if prez and step < n_f:
+            lp_steps = {float(opt_dp.state[p].get("step", 0)) for n, p in dp.net.named_parameters()
+                        if n.startswith("model_F.length_predictor.") and p in opt_dp.state and len(opt_dp.state[p])}
+            assert lp_steps == ({float(sum(use_z[:step + 1]))} if any(use_z[:step + 1]) else set()), (step, lp_steps)
+            assert len(opt_dp.state.get(dp.net.model_F.sos_token, {})) == 0
         scale = max(q.abs().max().item() for _, _, q in pairs)
         worst = max((g - q).abs().max().item() for _, g, q in pairs) / scale
         assert worst < 1e-4, (step, worst)
@@ -111,11 +132,11 @@ print("ok", rank)
 '''
 
 
-@pytest.mark.parametrize("mode", ["simple", "learnable", "learnable-2streams", "learnable-multibucket"])
+@pytest.mark.parametrize("mode", ["simple", "learnable", "learnable-2streams", "learnable-multibucket", "learnable-prez"])
 def test_two_rank_step_equals_single_process(tmp_path, mode):
     script = tmp_path / "w.py"
     script.write_text(WORKER)
-    port = {"simple": "29621", "learnable": "29622", "learnable-2streams": "29623", "learnable-multibucket": "29624"}[mode]
+    port = {"simple": "29621", "learnable": "29622", "learnable-2streams": "29623", "learnable-multibucket": "29624", "learnable-prez": "29625"}[mode]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2", OMP_NUM_THREADS="2", NAST_DDP_TIMEOUT_S="40")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, mode], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
