@@ -361,9 +361,13 @@ class _GateReplay:
         self.ops, self.tf = ops, tf
         self.prefix_of = {id(p): n[:-len("mlp.0.weight")] for n, p in model.net.named_parameters() if n.endswith("mlp.0.weight")}
         self.model = model
-        self.tags, self.ps = [], None
-        self.gates = {}            # (pass tag, parameter prefix) -> (gate [B,n,4d] bool, live rows [B,n] bool)   (CPU)
+        self.tags, self.ps, self.grad_on = [], None, []
+        self.gates = {}            # (pass tag, call index, parameter prefix) -> (gate [B,n,4d] bool, live rows [B,n] bool)   (CPU)
         self.flips, self.flip_max, self.compared, self.used = 0, 0.0, 0, set()
+        self.calls = {}            # (pass tag, parameter prefix) -> calls recorded so far
+        # oracle call index of a pass -> (HIP call index, first row, rows or None): d_step runs the two generated halves of
+        # the discriminator's input as ONE batch of 2B sentences where the oracle (and the reference) make two calls
+        self.call_map = {}
 
     # ---- HIP side ----
     def __enter__(self):
@@ -375,6 +379,8 @@ class _GateReplay:
 
         def ffn_forward(ctx, x, ln_w, ln_b, W1, b1, W2, b2):
             y = fwd(ctx, x, ln_w, ln_b, W1, b1, W2, b2)
+            if not (me.grad_on and me.grad_on[-1]):
+                return y                     # no backward follows (the generation passes of d_step): nothing to replay
             hmid = ctx.to_save[4]
             gate = hmid > 0
             ps = me.ps
@@ -387,9 +393,10 @@ class _GateReplay:
             else:
                 gate = gate.view(*x.shape[:-1], -1)
                 live = torch.ones(x.shape[:-1], dtype=torch.bool, device=gate.device)
-            key = (me.tags[-1], me.prefix_of[id(W1)])
-            assert key not in me.gates, key
-            me.gates[key] = (gate.cpu(), live.cpu())
+            tp = (me.tags[-1], me.prefix_of[id(W1)])
+            n = me.calls.get(tp, 0)
+            me.calls[tp] = n + 1
+            me.gates[(tp[0], n, tp[1])] = (gate.cpu(), live.cpu())
             return y
 
         def layer(orig, mask_arg):
@@ -405,10 +412,12 @@ class _GateReplay:
         def tagged(orig, tag_of):
             def run(*a, **k):
                 me.tags.append(tag_of(*a, **k))
+                me.grad_on.append(torch.is_grad_enabled())      # (inside a Function's forward grad mode is always off)
                 try:
                     return orig(*a, **k)
                 finally:
                     me.tags.pop()
+                    me.grad_on.pop()
             return run
 
         ops.FFNSublayerFn.forward = staticmethod(ffn_forward)
@@ -451,14 +460,22 @@ class _GateReplay:
                 finally:
                     tags.pop()
 
+            ocalls = {}
+
             def gates(prefix, pre):
-                if not tags or pre.dim() != 3:
+                if not tags or pre.dim() != 3 or not pre.requires_grad:
                     return None
                 prefix = ("model_D." if tags[-1] == "disc" else "model_F.") + prefix      # the oracle's prefixes are relative
-                ent = me.gates.get((tags[-1], prefix))
+                n = ocalls.get((tags[-1], prefix), 0)
+                ocalls[(tags[-1], prefix)] = n + 1
+                hip_n, row0, rows = me.call_map.get((tags[-1], n), (n, 0, None))
+                ent = me.gates.get((tags[-1], hip_n, prefix))
                 if ent is None:
                     return None
                 gate, live = ent
+                if rows is not None:                       # one half of a merged call, cut back to this call's own width
+                    gate, live = gate[row0:row0 + rows, :pre.shape[1]], live[row0:row0 + rows, :pre.shape[1]]
+                    assert not bool(ent[1][row0:row0 + rows, pre.shape[1]:].any()), "live rows beyond the oracle's width"
                 assert gate.shape == pre.shape, (prefix, gate.shape, pre.shape)
                 diff = ((pre > 0) != gate) & live.unsqueeze(-1)
                 n = int(diff.sum())
@@ -466,7 +483,7 @@ class _GateReplay:
                 me.compared += int(live.sum()) * gate.shape[-1]
                 if n:
                     me.flip_max = max(me.flip_max, float(pre.detach().abs()[diff].max()))
-                me.used.add((tags[-1], prefix))
+                me.used.add((tags[-1], hip_n, prefix))
                 return gate
 
             O.style_transformer, O.discriminator, O.RELU_GATES = tag_st, tag_disc, gates
@@ -477,9 +494,11 @@ class _GateReplay:
         return cm()
 
 
-def _oracle_vs_hip_step(cfg, B, seed=0, precision="fp32", name=None, replay_gates=True):
-    """One learnable f_step on fresh weights: HIP path vs the CPU oracle on identical weights, batch and Gumbel draw.
-    Returns a report: the 7 returned losses and the pre-clip gradient norm of both sides, and per tensor class the largest
+def _oracle_vs_hip_step(cfg, B, seed=0, precision="fp32", name=None, replay_gates=True, step="f", noise="identity"):
+    """One f_step (step="f") or d_step (step="d") on fresh weights: HIP path vs the CPU oracle on identical weights, batch and
+    Gumbel draws.  noise="device": the input noise of f_step is what the device NoiseLayer kernel produced for this batch
+    (blank / add / dropout at the reference's rates), fed to both sides; "identity": none.
+    Returns a report: the returned losses and the pre-clip gradient norm of both sides, and per tensor class the largest
     error of the (clipped) parameter gradients and of the post-Adam weights.  Written to gpurun_out/parity_<name>.json."""
     import json, os
     import nast_amd.utils as U
@@ -503,22 +522,54 @@ def _oracle_vs_hip_step(cfg, B, seed=0, precision="fp32", name=None, replay_gate
     dom = torch.tensor([0] * (B // 2) + [1] * (B - B // 2))
     inc = Storage(); inc.data = Storage()
     inc.data.sent, inc.data.sent_length, inc.data.domain = sent.cuda(), slen.cuda(), dom.cuda()
-    model.net.noiseLayer.forward = lambda w, l, rev_domain: (w, l)          # identity noise: same input on both sides
+    noise_tok, noise_len = sent, slen
+    if noise == "device":
+        # the real NoiseLayer kernel (nast_noise_i64, noise.py:60-194) on this batch, once; its output is then the input
+        # noise of BOTH sides (its own parity against the reference's stages: tests/test_noise_gpu.py)
+        with torch.no_grad():
+            cnt = model.net.noiseLayer.cnt
+            cnt.zero_()
+            cnt[:, 4:] = 1.0 / (cnt.shape[1] - 4)
+        torch.manual_seed(seed + 2)
+        fixed = model.net.noiseLayer(inc.data.sent.t(), inc.data.sent_length, rev_domain=1 - inc.data.domain)
+        assert fixed[0].is_cuda and not (fixed[0].shape[0] == sent.shape[1] and torch.equal(fixed[0].t().cpu(), sent)), "noise left the batch unchanged"
+        model.net.noiseLayer.forward = lambda w, l, rev_domain: fixed
+        noise_tok, noise_len = fixed[0].t().contiguous().cpu(), fixed[1].cpu()
+    else:
+        model.net.noiseLayer.forward = lambda w, l, rev_domain: (w, l)      # identity noise: same input on both sides
     model.net.model_F.train(); model.net.model_D.train()
     tr = O.Trainer(weights, O.Cfg(**cfg))
-    with torch.no_grad():
-        gen_lp = O.style_transformer(tr.w, tr.cfg, sent, slen, None, None, 1 - dom, True, 1.0, True)[0]
-    E = torch.empty_like(gen_lp).exponential_(generator=gen)
+    group = "model_F." if step == "f" else "model_D."
+    with torch.no_grad():          # the oracle decides the shapes of the Gumbel draws (generated lengths are data dependent)
+        styles = [1 - dom] if step == "f" else [dom, 1 - dom]
+        Es = []
+        for st in styles:
+            lp = O.style_transformer(tr.w, tr.cfg, sent, slen, None, None, st, True, 1.0, True)[0]
+            Es.append(torch.empty_like(lp).exponential_(generator=gen))
+            del lp
     replay = _GateReplay(model) if replay_gates else None
     import contextlib
-    with U.inject_noise([E.cuda()]), ops.gemm_precision(precision), (replay or contextlib.nullcontext()):
-        got = model.f_step(inc, 1.0, use_inference_z=True)
+    with U.inject_noise([e.cuda() for e in Es]), ops.gemm_precision(precision), (replay or contextlib.nullcontext()):
+        if step == "f":
+            got = model.f_step(inc, 1.0, use_inference_z=True)
+        else:
+            got = [model.d_step(inc, 1.0, use_inference_z=True)]
+    if replay and step == "d":
+        n_disc = max(n for (t, _), n in replay.calls.items() if t == "disc")
+        if cfg.get("disc", "Cond") == "Cond" and n_disc == 3:        # gold(raw), gold(rev), generated(raw ++ rev)
+            replay.call_map = {("disc", 2): (2, 0, B), ("disc", 3): (2, B, B)}
+        elif cfg.get("disc", "Cond") == "Multi" and n_disc == 2:     # gold, generated(raw ++ rev)
+            replay.call_map = {("disc", 1): (1, 0, B), ("disc", 2): (1, B, B)}
     with (replay.oracle(O) if replay else contextlib.nullcontext()):
-        ref = tr.f_step(sent, slen, dom, sent, slen, [E])
+        if step == "f":
+            ref = tr.f_step(sent, slen, dom, noise_tok, noise_len, Es)
+        else:
+            ref = [tr.d_step(sent, slen, dom, Es)]
     if replay:
         assert replay.used == set(replay.gates), set(replay.gates) - replay.used       # every recorded FFN found its oracle call
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
-    rep = {"cfg": {k: (int(v) if not isinstance(v, bool) else v) for k, v in cfg.items()}, "B": B, "precision": precision,
+    rep = {"cfg": {k: (v if isinstance(v, (bool, str)) else int(v)) for k, v in cfg.items()}, "B": B, "precision": precision,
+           "step": step + "_step", "noise": noise,
            "losses_hip": got.tolist(), "losses_oracle": ref.tolist(),
            "loss_rel_err": float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30) * (np.abs(ref) > 0))),
            "grad_norm_hip": float(model.last_grad_norm), "grad_norm_oracle": float(tr.last_norm)}
@@ -537,12 +588,18 @@ def _oracle_vs_hip_step(cfg, B, seed=0, precision="fp32", name=None, replay_gate
     # 1.2e-4 at 137 M parameters (measured: the oracle's clipped gradients have norm 5.0006 there, the HIP path's 5.00002 --
     # its norm kernel sums in float64).  The pre-clip norm is therefore checked against the float64 norm of the oracle's own
     # gradients, and the gradients are compared with each side's clip factor normalised to exactly 5 / norm.
-    rep["grad_norm_oracle_fp64"] = rep["clipped_norm_fp64_oracle"] * (rep["grad_norm_oracle"] + 1e-6) / 5.0
+    rep["clipped"] = bool(rep["grad_norm_oracle"] > 5.0 and rep["grad_norm_hip"] > 5.0)
+    if rep["clipped"]:
+        rep["grad_norm_oracle_fp64"] = rep["clipped_norm_fp64_oracle"] * (rep["grad_norm_oracle"] + 1e-6) / 5.0
+        fix_hip, fix_ref = 5.0 / rep["clipped_norm_fp64_hip"], 5.0 / rep["clipped_norm_fp64_oracle"]
+    else:                                              # (a discriminator step below the clip threshold: gradients are unscaled)
+        assert rep["grad_norm_oracle"] <= 5.0 and rep["grad_norm_hip"] <= 5.0, (rep["grad_norm_oracle"], rep["grad_norm_hip"])
+        rep["grad_norm_oracle_fp64"] = rep["clipped_norm_fp64_oracle"]
+        fix_hip = fix_ref = 1.0
     rep["grad_norm_rel_err_vs_oracle_fp32"] = rep["grad_norm_rel_err"]
     rep["grad_norm_rel_err"] = abs(rep["grad_norm_hip"] - rep["grad_norm_oracle_fp64"]) / rep["grad_norm_oracle_fp64"]
-    fix_hip, fix_ref = 5.0 / rep["clipped_norm_fp64_hip"], 5.0 / rep["clipped_norm_fp64_oracle"]
     gmax *= fix_ref
-    lr = cfg.get("lr_F", 1e-4)
+    lr = cfg.get("lr_F" if step == "f" else "lr_D", 1e-4)
     classes = {}
     for k, gr in gref.items():
         p = named[k]
@@ -567,7 +624,7 @@ def _oracle_vs_hip_step(cfg, B, seed=0, precision="fp32", name=None, replay_gate
             c["weight_err_solid_vs_tensor_max"] = max(c["weight_err_solid_vs_tensor_max"], float(werr[solid].max()) / wmax)
         c["tensors"] += 1
     for k, p in named.items():
-        if k.startswith("model_F.") and k not in gref:
+        if k.startswith(group) and k not in gref:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{k} has a gradient the oracle lacks"
     rep["classes"] = classes
     rep["grad_err_vs_tensor_max"] = max(c["grad_err_vs_tensor_max"] for c in classes.values())
@@ -622,6 +679,31 @@ def test_bench_shape_step_vs_oracle():
 def test_bench_shape_step_vs_oracle_full_batch():
     """The same at the benchmarked batch: 512 sentences (two streams, packed rows, split-K weight gradients with K = all rows)."""
     _assert_step_parity(_oracle_vs_hip_step(BENCH_CFG, B=512, seed=3, name="bench_b512"), 1e-4)
+
+
+SIMPLE_CFG = dict(V=9600, d=256, h=4, N=4, L=16, learnable=False)      # BASELINE.json configs[1]
+
+
+def test_bench_shape_f_step_with_device_noise_vs_oracle():
+    """f_step at the bench shape, 64 sentences, with the REAL input noise: the device NoiseLayer's output for the batch
+    (blank 0.1, add 1/0.95-1, dropout 0.05; run.py:90-95) is the noisy source of both sides (seq2seq.py:438-451)."""
+    _assert_step_parity(_oracle_vs_hip_step(BENCH_CFG, B=64, seed=7, name="bench_b64_device_noise", noise="device"), 1e-4)
+
+
+@pytest.mark.parametrize("B,disc", [(64, "Cond"), (512, "Cond"), (64, "Multi")])
+def test_bench_shape_d_step_vs_oracle(B, disc):
+    """d_step (seq2seq.py:551-642) at the bench shape: both styles generated as one 2B batch, two Gumbel draws, the gold
+    half on the second stream from the decode hook, the generated halves through the discriminator as one packed batch --
+    loss, gradient norm, every discriminator gradient and the post-Adam weights at 1e-4, Cond and Multi."""
+    cfg = dict(BENCH_CFG, disc=disc)
+    _assert_step_parity(_oracle_vs_hip_step(cfg, B=B, seed=11 + B, name=f"bench_d_step_b{B}_{disc.lower()}", step="d"), 1e-4)
+
+
+@pytest.mark.parametrize("step", ["f", "d"])
+def test_configs1_simple_step_vs_oracle(step):
+    """BASELINE.json configs[1] at full size: simple alignment, V=9600, d=256, 4 layers, L=16, 64 sentences -- the padded
+    execution (lengths read off the argmax of the soft tokens, seq2seq.py:545-549), f_step and d_step."""
+    _assert_step_parity(_oracle_vs_hip_step(SIMPLE_CFG, B=64, seed=5, name=f"configs1_simple_{step}_step", step=step), 1e-4)
 
 
 def test_stress_shape_step_vs_oracle():
