@@ -35,6 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 GFLOP_PER_SENTENCE = {("learnable", 32): 10.1, ("learnable", 16): 5.12, ("simple", 16): 3.80}
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable by a float4 copy)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 
 
 def synth_incoming(B, L, V, seed, device):
@@ -292,105 +293,242 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    from nast_amd import _lib
+    lib = _lib.load()
+    init_state = {k: v.detach().clone() for k, v in model.net.state_dict().items()}
+
+    def reset(m=None, state=None, seed=None):
+        """Every leg below starts where the headline run started: initial weights, empty Adam state, the rank's seeds, no captured
+        graphs -- so that no figure depends on which legs ran before it (the generated lengths, hence the widths of the cycle pass
+        and of the discriminator's inputs, follow the weights)."""
+        m, state = m or model, state or init_state
+        with torch.no_grad():
+            for k, v in m.net.state_dict().items():
+                v.copy_(state[k])
+        for opt in (m.optimizer_F, m.optimizer_D):
+            opt.state.clear()
+            opt._tables.clear()
+            opt._dev_step = None
+        m._graphs = None
+        m.graph_steps = False
+        np.random.seed(100 + rank if seed is None else seed)
+        torch.manual_seed(100 + rank if seed is None else seed)
+        torch.cuda.manual_seed(100 + rank if seed is None else seed)
+
+    def timed(fn, n, warm=4):
+        for i in range(warm):
+            fn(i)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(n):
+            fn(warm + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+
+    def gemm_roofline(m, fn, n, warm, peak, what):
+        """HIP-event timing around every launch of the tiled GEMM kernel over n steps of fn (two-stream overlap off, so an event
+        pair times one kernel alone) -> achieved TFLOP/s against `peak`, plus the other armed families."""
+        saved, m.overlap_passes = m.overlap_passes, False
+        try:
+            for i in range(warm):
+                fn(i)
+            torch.cuda.synchronize()
+            lib.nast_prof_begin(0)      # every family: 1 GEMM, 2 vocabulary row kernels, 3 alignment DP, 4 small-M GEMM, 5 LSE alignment
+            for i in range(n):
+                fn(warm + i)
+            torch.cuda.synchronize()
+        finally:
+            m.overlap_passes = saved
+        ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        lib.nast_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
+        if ms.value <= 0:
+            return None
+        ach = fl.value / (ms.value * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": what, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None, "launches": int(cnt.value), "steps": n, "avg_launch_us": round(ms.value * 1e3 / max(cnt.value, 1), 2),
+                "avg_launch_gflop": round(fl.value / max(cnt.value, 1) / 1e9, 4), "gemm_ms_per_step": round(ms.value / n, 3)}
+
+    def family(kind):
+        ms, wk, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        lib.nast_prof_get(kind, ctypes.byref(ms), ctypes.byref(wk), ctypes.byref(cnt))
+        return ms.value, wk.value, int(cnt.value)
+
+    f_fn = lambda i: model.f_step(batches[i % len(batches)], 1.0, use_inference_z=True)      # noqa: E731
+    d_fn = lambda i: model.d_step(batches[i % len(batches)], 1.0, use_inference_z=True)      # noqa: E731
+
+    roofline = None
+    roofline_error = None
+    gemm_flops_per_step = None
+    if not a.no_roofline:
+        try:
+            # A second pass over the SAME steps as the headline run (initial weights, the same warm-up, then the timed steps'
+            # first five) with event timing armed; kept out of the pass that produces `value`.  EVERY rank runs the steps (they
+            # contain the gradient all-reduce); rank 0 reports its own kernels.
+            n_roof = min(a.steps, 5)
+            reset()
+            roofline = gemm_roofline(model, f_fn, n_roof, a.warmup, PEAK_FP32_MFMA_TFLOPS, "nast_gemm_f32_kernel (tiled fp32 MFMA GEMM, 2/3 of kernel time)")
+            if rank == 0 and roofline:
+                ms1, fl1, n1 = family(1)
+                ms4, fl4, n4 = family(4)      # the small-M GEMM kernel of the greedy decode (M = sentences, latency-bound)
+                gemm_flops_per_step = (fl1 + fl4) / n_roof      # GEMM FLOP actually issued per step
+                if ms4 > 0:
+                    roofline["decode_small_m_gemm"] = {"achieved": round(fl4 / (ms4 * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                                       "launches": n4, "avg_launch_us": round(ms4 * 1e3 / max(n4, 1), 2)}
+                    allf = (fl1 + fl4) / ((ms1 + ms4) * 1e-3) / 1e12
+                    roofline["gemm_family_all"] = {"achieved": round(allf, 2), "frac": round(allf / PEAK_FP32_MFMA_TFLOPS, 4), "launches": n1 + n4}
+                # the HBM-bound families next to it: algorithmic bytes (SURVEY.md section 8d) / HIP-event time
+                hbm = {}
+                for kind, name in ((2, "vocab_row_kernels"), (3, "alignment_dp")):
+                    ms, wk, n = family(kind)
+                    if ms > 0:
+                        gbs = wk / (ms * 1e-3) / 1e9
+                        hbm[name] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                     "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
+                                     "algorithmic_bytes_per_launch": round(wk / max(n, 1))}
+                roofline["hbm_bound_kernels"] = hbm
+                # HBM-side bytes per launch of the same kernel families from the committed PMC passes (tools/pmc_traffic.py:
+                # FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections of the microarchitecture guide), newest round first
+                here = os.path.dirname(os.path.abspath(__file__))
+                tpath = next((q for q in (os.path.join(here, "profiles", f"r{r}_pmc_traffic.json") for r in (3, 2)) if os.path.exists(q)), None)
+                if B == 512 and learnable and tpath:
+                    with open(tpath) as f:
+                        t = json.load(f)
+                    if "nast_gemm_f32_kernel" in t:
+                        roofline["traffic"] = round(t["nast_gemm_f32_kernel"]["bytes_per_launch"])
+                        roofline["traffic_unit"] = f"bytes per launch, PMC passes recorded in profiles/{os.path.basename(tpath)[:-5]}.txt"
+                    # the same launches as `achieved` counts: all four row kernels AND the NLL gather
+                    keys = ("nast_log_softmax_fwd_rr_kernel", "nast_softmax_bwd_rr_kernel", "nast_nll_log_softmax_bwd_kernel",
+                            "nast_gumbel_softmax_fwd_rr_kernel", "nast_nll_gather_kernel")
+                    fams = [t[k] for k in keys if k in t]
+                    if fams and "vocab_row_kernels" in hbm:
+                        hbm["vocab_row_kernels"]["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
+        except Exception as e:      # noqa: BLE001  (the headline line is printed regardless)
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            roofline_error = f"{type(e).__name__}: {e}"[:300]
+            model.overlap_passes = not a.no_overlap
+
     also = None
     if world == 1 and B > 64 and not a.no_also:
         # (optional legs: a failure in one of them must not cost the headline line; what was measured so far is kept)
         also = {}
         try:
-            # the same step at the reference's batch size (64 sentences)
-            small = [synth_incoming(64, L, cfg["V"], 5000 + i, "cuda") for i in range(4)]
-            for i in range(3):
-                model.f_step(small[i % 4], 1.0, use_inference_z=True)
-            torch.cuda.synchronize()
-            n_small = min(a.steps, 10)
-            t1 = time.perf_counter()
-            for i in range(n_small):
-                model.f_step(small[i % 4], 1.0, use_inference_z=True)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / n_small
-            also["bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_small}
-
-            def graphed(m, data, n, which="f_step"):
-                """the same step replayed from one HIP graph (nast_amd/graph.py): 2 eager fixed-width steps, capture, then timing"""
-                m.graph_steps = True
-                step = getattr(m, which)
-                try:
-                    for i in range(4):
-                        step(data[i % 4], 1.0, use_inference_z=True)
-                    torch.cuda.synchronize()
-                    t = time.perf_counter()
-                    for i in range(n):
-                        step(data[i % 4], 1.0, use_inference_z=True)
-                    torch.cuda.synchronize()
-                    return (time.perf_counter() - t) / n
-                finally:
-                    m.graph_steps = False
-
-            dtg = graphed(model, small, max(n_small, 10))
-            also["bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3),
-                                  "note": "whole f_step replayed from one HIP graph (Seq2seq.graph_steps = True)"}
-            # the discriminator step at 64 sentences, eager and replayed, and the reference's schedule (10 d_step : 5 f_step) on both
-            for i in range(3):
-                model.d_step(small[i % 4], 1.0, use_inference_z=True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(n_small):
-                model.d_step(small[i % 4], 1.0, use_inference_z=True)
-            torch.cuda.synchronize()
-            dtd = (time.perf_counter() - t1) / n_small
-            dtdg = graphed(model, small, max(n_small, 10), "d_step")
-            also["bs64_d_step"] = {"ms_per_step": round(dtd * 1e3, 3), "ms_per_step_graph": round(dtdg * 1e3, 3)}
-            also["bs64_schedule_blend_10d_5f"] = {"value": round(15 * 64 / (10 * dtd + 5 * dt), 2), "value_graph": round(15 * 64 / (10 * dtdg + 5 * dtg), 2),
-                                                  "unit": "sentences/s"}
-
-            def timed(fn, n):
-                for _ in range(4):       # (these legs follow the 64-sentence and graph legs: let the caching allocator settle again)
-                    fn(0)
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for i in range(n):
-                    fn(i)
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t) / n
-
-            # the step without its optimizer, measured right behind the headline pass (clip + Adam skipped; forward + both backwards only)
+            n_leg = min(a.steps, 8)
+            # the step without its optimizer (clip + Adam skipped; forward + both backwards only): same start, same batches
+            reset()
             step_fn = model.optimizer_F.clip_and_step
             model.optimizer_F.clip_and_step = lambda max_norm=None, capturing=False: None
             try:
-                dt_fb = timed(lambda i: model.f_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
+                dt_fb = timed(f_fn, n_leg, a.warmup)
             finally:
                 model.optimizer_F.clip_and_step = step_fn
-            also["fwd_bwd_only"] = {"value": round(B / dt_fb, 2), "unit": "sentences/s", "ms_per_step": round(dt_fb * 1e3, 3), "batch": B}
-            # the discriminator step (seq2seq.py:551-642) on the same batches
-            dt = timed(lambda i: model.d_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
-            also["d_step"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B}
+            also["fwd_bwd_only"] = {"value": round(B / dt_fb, 2), "unit": "sentences/s", "ms_per_step": round(dt_fb * 1e3, 3), "batch": B,
+                                    "note": "weights stay at their initial values here, which generate longer sentences than the weights the "
+                                            "headline run reaches after a few Adam steps: the cycle pass and the discriminator are wider"}
+            # the discriminator step (seq2seq.py:551-642) on the same batches, from the same initial weights
+            reset()
+            dt_d = timed(d_fn, n_leg, a.warmup)
+            also["d_step"] = {"value": round(B / dt_d, 2), "unit": "sentences/s", "ms_per_step": round(dt_d * 1e3, 3), "batch": B}
+            reset()
+            rd = gemm_roofline(model, d_fn, min(a.steps, 5), a.warmup, PEAK_FP32_MFMA_TFLOPS, "nast_gemm_f32_kernel in d_step")
+            if rd:
+                also["d_step"]["roofline"] = rd
             f_ms = elapsed / a.steps
             # SURVEY.md section 8d: the reference schedule runs 10 d_step per 5 f_step (run.py:133-134)
-            also["schedule_blend_10d_5f"] = {"value": round(15 * B / (10 * dt + 5 * f_ms), 2), "unit": "sentences/s"}
+            also["schedule_blend_10d_5f"] = {"value": round(15 * B / (10 * dt_d + 5 * f_ms), 2), "unit": "sentences/s"}
+
+            # SURVEY.md section 8d cfg-3: the same steps at the reference's batch size (64 sentences), eager and replayed from a HIP graph
+            small = [synth_incoming(64, L, cfg["V"], 5000 + i, "cuda") for i in range(4)]
+            sf = lambda i: model.f_step(small[i % 4], 1.0, use_inference_z=True)      # noqa: E731
+            sd = lambda i: model.d_step(small[i % 4], 1.0, use_inference_z=True)      # noqa: E731
+            n_small = min(a.steps, 10)
+
+            def graphed(m, fn, n):
+                """the same step replayed from one HIP graph (nast_amd/graph.py): eager fixed-width steps, capture, then timing"""
+                m.graph_steps = True
+                try:
+                    return timed(fn, n, 4)
+                finally:
+                    m.graph_steps = False
+
+            reset(); dt = timed(sf, n_small, 3)
+            also["bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "steps": n_small}
+            reset(); dtg = graphed(model, sf, max(n_small, 10))
+            also["bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3),
+                                  "note": "whole f_step replayed from one HIP graph (Seq2seq.graph_steps = True)"}
+            reset(); dtd = timed(sd, n_small, 3)
+            reset(); dtdg = graphed(model, sd, max(n_small, 10))
+            also["bs64_d_step"] = {"ms_per_step": round(dtd * 1e3, 3), "ms_per_step_graph": round(dtdg * 1e3, 3)}
+            also["bs64_schedule_blend_10d_5f"] = {"value": round(15 * 64 / (10 * dtd + 5 * dt), 2), "value_graph": round(15 * 64 / (10 * dtdg + 5 * dtg), 2),
+                                                  "unit": "sentences/s"}
+            if a.precision == "fp32":
+                # north_star's bf16 variant: GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 accumulate), same step from the same start
+                reset()
+                _ops.set_gemm_precision("bf16")
+                try:
+                    dt = timed(f_fn, n_leg, a.warmup)
+                    reset()
+                    rb = gemm_roofline(model, f_fn, min(a.steps, 5), a.warmup, PEAK_BF16_MFMA_TFLOPS, "tiled GEMM kernel, bf16 MFMA operands")
+                finally:
+                    _ops.set_gemm_precision("fp32")
+                also["bf16_gemm_variant"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B,
+                                             "dtype": "bf16 MFMA operands, fp32 accumulate", "roofline": rb}
+            reset()
+
             # BASELINE.json configs[1]: simple alignment, YELP-shaped batch (64 sentences, len <= 16)
             cfg1 = dict(V=9600, d=256, h=4, N=4, L=16, learnable=False)
             m1 = build_model(cfg1, "cuda")
+            st1 = {k: v.detach().clone() for k, v in m1.net.state_dict().items()}
             b1 = [synth_incoming(64, 16, 9600, 7000 + i, "cuda") for i in range(4)]
-            dt = timed(lambda i: m1.f_step(b1[i % 4], 1.0, use_inference_z=True), min(a.steps, 10))
+            f1 = lambda i: m1.f_step(b1[i % 4], 1.0, use_inference_z=True)      # noqa: E731
+            dt = timed(f1, min(a.steps, 10))
             also["configs1_simple_L16_bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3)}
-            dtg = graphed(m1, b1, 10)
+            reset(m1, st1)
+            dtg = graphed(m1, f1, 10)
             also["configs1_simple_L16_bs64_graph"] = {"value": round(64 / dtg, 2), "unit": "sentences/s", "ms_per_step": round(dtg * 1e3, 3)}
-            del m1
-            # BASELINE configs[4] (stress shape: V=32000, d=1024, h=16, 8 layers, len<=128, learnable) at 64 sentences
+            del m1, st1
+            # BASELINE configs[4] (stress shape: V=32000, d=1024, h=16, 8 layers, len<=128, learnable) at 64 sentences, fp32 and with
+            # bf16 MFMA operands, each with the tiled GEMM kernel's roofline fraction at d = 1024
             cfg4 = dict(V=32000, d=1024, h=16, N=8, L=128, learnable=True)
             m4 = build_model(cfg4, "cuda")
+            st4 = {k: v.detach().clone() for k, v in m4.net.state_dict().items()}
             b4 = [synth_incoming(64, 128, 32000, 9000 + i, "cuda") for i in range(2)]
-            dt = timed(lambda i: m4.f_step(b4[i % 2], 1.0, use_inference_z=True), 3)
-            also["configs4_stress_L128_bs64"] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3)}
-            del m4, b4
+            f4 = lambda i: m4.f_step(b4[i % 2], 1.0, use_inference_z=True)      # noqa: E731
+            leg = {}
+            for prec, peak in (("fp32", PEAK_FP32_MFMA_TFLOPS), ("bf16", PEAK_BF16_MFMA_TFLOPS)):
+                _ops.set_gemm_precision(prec)
+                try:
+                    reset(m4, st4)
+                    dt = timed(f4, 3, 2)
+                    reset(m4, st4)
+                    r4 = gemm_roofline(m4, f4, 2, 2, peak, f"tiled GEMM kernel at d=1024, {prec} MFMA operands")
+                finally:
+                    _ops.set_gemm_precision(a.precision)
+                leg[prec] = {"value": round(64 / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "roofline": r4}
+            also["configs4_stress_L128_bs64"] = leg["fp32"]
+            also["configs4_stress_L128_bs64_bf16"] = leg["bf16"]
+            del m4, b4, st4
             torch.cuda.empty_cache()
-            if a.precision == "fp32":
-                # north_star's bf16 variant: GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 storage + accumulate), same step
-                _ops.set_gemm_precision("bf16")
-                dt = timed(lambda i: model.f_step(batches[i % 4], 1.0, use_inference_z=True), min(a.steps, 8))
-                _ops.set_gemm_precision("fp32")
-                also["bf16_gemm_variant"] = {"value": round(B / dt, 2), "unit": "sentences/s", "ms_per_step": round(dt * 1e3, 3), "batch": B,
-                                             "dtype": "bf16 MFMA operands, fp32 accumulate/storage"}
+
+            # north_star (b) names a log-sum-exp alignment DP; the reference has none (SURVEY section 0): the extension kernels
+            # (parity unpinned, not part of the step) timed on cost tables of the bench shape and of configs[4]'s
+            lse = {}
+            for name, (Bq, Tq) in (("B512_T32_S32", (512, 32)), ("B64_T128_S128", (64, 128))):
+                g = torch.Generator(device="cuda").manual_seed(3)
+                cost = torch.rand(Bq, Tq, Tq, device="cuda", generator=g).requires_grad_(True)
+                cost0 = torch.rand(Bq, Tq, device="cuda", generator=g).requires_grad_(True)
+                ln = torch.full((Bq,), Tq, device="cuda", dtype=torch.int64)
+                for it in range(4):
+                    if it == 1:
+                        lib.nast_prof_begin(5)
+                    _ops.align_lse(cost0, cost, ln, ln, 0.5).sum().backward()
+                torch.cuda.synchronize()
+                lib.nast_prof_end(None, None, None)
+                ms, wk, n = family(5)
+                lse[name] = {"fwd_plus_bwd_us": round(ms * 1e3 / 3, 2), "achieved": round(wk / (ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                             "frac_of_hbm_peak": round(wk / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launches": n}
+            also["alignment_lse_extension"] = dict(lse, note="nast_align_lse_fwd/bwd_f32: latency-bound (one wavefront per sentence, T dependent "
+                                                             "steps); extension with no counterpart in the reference, outside the step")
         except Exception as e:      # noqa: BLE001
             import traceback
             traceback.print_exc(file=sys.stderr)
@@ -399,71 +537,6 @@ def main():
             _ops.set_gemm_precision(a.precision)
             torch.cuda.synchronize()
 
-    roofline = None
-    roofline_error = None
-    gemm_flops_per_step = None
-    if not a.no_roofline:
-        try:
-            # second pass over the same steps with HIP-event timing armed around every launch of the dominant
-            # kernel family (grouped fp32 MFMA GEMM); kept out of the pass that produces `value`.  EVERY rank runs
-            # the steps (they contain the gradient all-reduce); rank 0 reports its own kernels.
-            from nast_amd import _lib
-            lib = _lib.load()
-            # The two-stream overlap is switched off for this pass: an event pair around a launch measures that
-            # kernel's own duration only while nothing else shares the GPU with it.
-            model.overlap_passes = False
-            lib.nast_prof_begin(0)        # every family: 1 GEMM, 2 vocabulary row kernels, 3 alignment DP
-            run(min(a.steps, 5), offset=a.warmup)
-            torch.cuda.synchronize()
-            model.overlap_passes = not a.no_overlap
-            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-            lib.nast_prof_end(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
-            if rank == 0 and ms.value > 0:
-                ach = fl.value / (ms.value * 1e-3) / 1e12
-                roofline = {"bound": "mfma", "kernel": "nast_gemm_f32_kernel (tiled fp32 MFMA GEMM, 78 % of kernel time)",
-                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                            "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2),
-                            "avg_launch_gflop": round(fl.value / max(n.value, 1) / 1e9, 4)}
-                # the small-M GEMM kernel of the greedy decode (M = sentences, latency-bound) and the family as a whole
-                ms4, fl4, n4 = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
-                lib.nast_prof_get(4, ctypes.byref(ms4), ctypes.byref(fl4), ctypes.byref(n4))
-                gemm_flops_per_step = (fl.value + fl4.value) / max(min(a.steps, 5), 1)      # GEMM FLOP actually issued per step
-                if ms4.value > 0:
-                    roofline["decode_small_m_gemm"] = {"achieved": round(fl4.value / (ms4.value * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
-                                                       "launches": int(n4.value), "avg_launch_us": round(ms4.value * 1e3 / max(n4.value, 1), 2)}
-                    allf = (fl.value + fl4.value) / ((ms.value + ms4.value) * 1e-3) / 1e12
-                    roofline["gemm_family_all"] = {"achieved": round(allf, 2), "frac": round(allf / PEAK_FP32_MFMA_TFLOPS, 4),
-                                                   "launches": int(n.value + n4.value)}
-                # the HBM-bound families next to it: algorithmic bytes / HIP-event time
-                hbm = {}
-                for kind, name in ((2, "vocab_row_kernels"), (3, "alignment_dp")):
-                    lib.nast_prof_get(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
-                    if ms.value > 0:
-                        gbs = fl.value / (ms.value * 1e-3) / 1e9
-                        hbm[name] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                     "launches": int(n.value), "avg_launch_us": round(ms.value * 1e3 / max(n.value, 1), 2)}
-                roofline["hbm_bound_kernels"] = hbm
-                # HBM-side bytes per launch of the same kernel family from the committed PMC passes (tools/pmc_traffic.py,
-                # profiles/r2_pmc_traffic.txt: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections of the microarchitecture guide)
-                tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
-                if B == 512 and learnable and os.path.exists(tpath):
-                    with open(tpath) as f:
-                        t = json.load(f)
-                    fams = [t[k] for k in ("nast_gemm_f32_kernel",) if k in t]
-                    if fams:
-                        roofline["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
-                        roofline["traffic_unit"] = "bytes per launch, PMC passes recorded in profiles/r2_pmc_traffic.txt"
-                    for name, keys in (("vocab_row_kernels", ("nast_log_softmax_fwd_rr_kernel", "nast_softmax_bwd_rr_kernel", "nast_nll_log_softmax_bwd_kernel",
-                                                              "nast_gumbel_softmax_fwd_rr_kernel")),):
-                        fams = [t[k] for k in keys if k in t]
-                        if fams and name in hbm:
-                            hbm[name]["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
-        except Exception as e:      # noqa: BLE001  (the headline line is printed regardless)
-            import traceback
-            traceback.print_exc(file=sys.stderr)
-            roofline_error = f"{type(e).__name__}: {e}"[:300]
-            model.overlap_passes = not a.no_overlap
     if dist_on:
         dist.barrier()
         import nast_amd.ddp as _ddp

@@ -366,8 +366,11 @@ extern "C" int nast_align_lse_fwd_f32(const float* cost0, const float* cost, con
   NAST_REQUIRE(tau > 0.f, "nast_align_lse_fwd_f32: tau must be > 0");
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(cost0 && cost && origin_length && target_length && value && alpha, "nast_align_lse_fwd_f32: NULL pointer");
+  nast_prof_before(5, (hipStream_t)stream);
   hipLaunchKernelGGL(nast_align_lse_fwd_kernel, dim3(B), dim3(64), (size_t)2 * (S + 3) * 4, (hipStream_t)stream, cost0, cost,
                      origin_length, target_length, tau, value, alpha, T, S);
+  // algorithmic bytes per sentence: the cost table read once, the forward table alpha written once, cost0, value, 2 lengths
+  nast_prof_after(5, (hipStream_t)stream, (double)B * (8.0 * T * S + 4.0 * T + 4.0 + 16.0));
   NAST_CHECK_LAUNCH("nast_align_lse_fwd_f32");
   return NAST_OK;
 }
@@ -380,8 +383,11 @@ extern "C" int nast_align_lse_bwd_f32(const float* cost0, const float* cost, con
   if (B == 0) return NAST_OK;
   NAST_REQUIRE(cost0 && cost && origin_length && target_length && value && alpha && dvalue && dcost0 && dcost,
                "nast_align_lse_bwd_f32: NULL pointer");
+  nast_prof_before(5, (hipStream_t)stream);
   hipLaunchKernelGGL(nast_align_lse_bwd_kernel, dim3(B), dim3(64), (size_t)2 * (S + 3) * 4, (hipStream_t)stream, cost0, cost,
                      origin_length, target_length, tau, value, alpha, dvalue, dcost0, dcost, T, S);
+  // cost and alpha read once, dcost written once, cost0 / dcost0, value / dvalue, 2 lengths
+  nast_prof_after(5, (hipStream_t)stream, (double)B * (12.0 * T * S + 8.0 * T + 8.0 + 16.0));
   NAST_CHECK_LAUNCH("nast_align_lse_bwd_f32");
   return NAST_OK;
 }
