@@ -686,7 +686,11 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
   // split-K plan.  Work is counted in K-tiles per workgroup.  The group should (a) put >= ~3 workgroups on each
   // of the 256 CUs and (b) give every workgroup about the same amount of work, so a K-heavy member (a weight
   // gradient: K = all rows of the batch; the generator dgrad / soft-token embedding: K = vocabulary) is cut
-  // into slices no longer than the members that cannot be cut.  Atomically accumulated outputs are cut
+  // into slices of about work / TARGET_WGS K-tiles.  (Until round 3 a slice was also capped at the length of the longest
+  // member that cannot be cut -- "every workgroup the same length".  With a K = 256 dgrad beside it that cut an FFN weight
+  // gradient into 39 slices, i.e. 41 MB of fp32 atomic adds per launch against the chip's ~1.3 TB/s atomic rate; long slices
+  // are dispatched first and the short workgroups fill in behind them, so the cap bought no balance: 86.2 -> 89.4 TFLOP/s
+  // over the step's GEMM launches without it.)  Atomically accumulated outputs are cut
   // directly; plain outputs are zeroed here and switched to atomic adds (bias/residual go to slice 0).
   constexpr int MIN_KT = 256 / BK;                       // at least K = 256 per slice
   constexpr int TARGET_WGS = (BM >= 128) ? 768 : 1024;
@@ -708,8 +712,11 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
     work += (long long)P.tiles_m[i] * P.tiles_n[i] * nkt_of[i];
     if (!can_split[i] && nkt_of[i] > max_unsplit) max_unsplit = nkt_of[i];
   }
-  long long target = (work + TARGET_WGS - 1) / TARGET_WGS;
-  if (max_unsplit > 0 && target > max_unsplit) target = max_unsplit;
+  static const int target_wgs_env = [] { const char* e = getenv("NAST_GEMM_TARGET_WGS"); return e ? atoi(e) : 0; }();   // tuning aid
+  static const int split_cap = [] { const char* e = getenv("NAST_GEMM_SPLIT_CAP"); return e ? atoi(e) : 0; }();            // tuning aid: cap on a slice, in % of the longest uncut member (0 = none)
+  const int target_wgs = target_wgs_env > 0 ? target_wgs_env : TARGET_WGS;
+  long long target = (work + target_wgs - 1) / target_wgs;
+  if (max_unsplit > 0 && split_cap > 0 && target > (long long)max_unsplit * split_cap / 100) target = (long long)max_unsplit * split_cap / 100;
   if (target < MIN_KT) target = MIN_KT;
   // longest workgroups first (dispatch follows blockIdx): the tail of the launch is then made of short ones
   int order[NAST_GEMM_MAX_GROUP];
