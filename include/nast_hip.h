@@ -338,6 +338,14 @@ int nast_lp_decode_f32(const nast_lp_decode_args* args, int* steps_out, void* st
 #define NAST_LP_DECODE_STATIC_BYTES (64u << 20)
 int nast_lp_decode_static_f32(const nast_lp_decode_args* args, int* steps_out, void* stream);
 
+/* nast_lp_decode_f32 runs eligible shapes (d = 256, 4 heads, d_ff = 1024, <= 4 layers, L and S1 <= 36, <= 2048 sentences;
+ * NAST_DECODE_CLUSTER=0 turns it off) as ONE persistent launch of 8 clusters x 32 workgroups with cluster barriers between
+ * the operations (csrc/decode_cluster.hip; same loop as transformer.py:525-570).  A barrier whose poll runs out (1 s: some
+ * workgroup of the grid was not resident, e.g. under a CU mask) raises a sticky flag on the device instead of hanging; the
+ * positions of that call are then garbage.  *status_out = 0: no such event on the current device since the library was
+ * loaded, 1: there was one.  Synchronous (reads one device word): call it where the caller synchronises anyway. */
+int nast_lp_decode_cluster_status(int* status_out);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser side (seq2seq.py:536-537, :637-638): multi-tensor L2 norm + clip + Adam in few launches.
  * ptrs are device arrays of device pointers (one entry per parameter tensor), sizes int64 element counts.

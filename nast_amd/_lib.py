@@ -83,6 +83,7 @@ SIGNATURES = {
     "nast_lp_decode_workspace_bytes": [_i] * 6,
     "nast_lp_decode_f32": [C.POINTER(LPDecodeArgs), C.POINTER(C.c_int), c_fp],
     "nast_lp_decode_static_f32": [C.POINTER(LPDecodeArgs), C.POINTER(C.c_int), c_fp],
+    "nast_lp_decode_cluster_status": [C.POINTER(C.c_int)],
     "nast_multi_sqnorm_f32": [c_fp, c_fp, _i, c_fp, c_fp, c_fp, _i, _i, c_fp],
     "nast_multi_adam_f32": [c_fp] * 5 + [_i, c_fp] + [_f] * 8 + [c_fp, c_fp, c_fp, _i, _i, c_fp],
     "nast_prof_begin": [_i],

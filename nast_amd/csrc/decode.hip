@@ -47,6 +47,7 @@ struct Ws {
   int64_t* now_pos;
   int* done;
   uint8_t* mask;
+  unsigned* sync;
   size_t total;
 };
 
@@ -75,6 +76,7 @@ Ws carve(float* base, int B, int S1, int d, int dff, int L, int nl, int h) {
   w.now_pos = reinterpret_cast<int64_t*>(take((size_t)B * 2));
   w.done = reinterpret_cast<int*>(take(16));
   w.mask = reinterpret_cast<uint8_t*>(take(((size_t)B * S1 + 3) / 4));
+  w.sync = reinterpret_cast<unsigned*>(take(8 * 32));      // arrival counters of the cluster kernel (decode_cluster.hip)
   w.total = o * sizeof(float);
   return w;
 }
@@ -95,6 +97,11 @@ extern "C" int64_t nast_lp_decode_workspace_bytes(int B, int S1, int d, int dff,
 bool nast_lp_decode_fused_eligible(const nast_lp_decode_args* A);                                        // decode_fused.hip
 int nast_lp_decode_fused_launch(const nast_lp_decode_args* A, const float* cand, const float* KC, const float* kunk, const float* mk,
                                 const float* mv, float* kc, float* vc, int* steps_dev, hipStream_t s);
+
+bool nast_lp_decode_cluster_eligible(const nast_lp_decode_args* A);                                      // decode_cluster.hip
+int nast_lp_decode_cluster_launch(const nast_lp_decode_args* A, const float* cand, const float* KC, const float* kunk, const float* mk,
+                                  const float* mv, float* kc, float* vc, float* x, float* q, float* a, float* x1, float* x2, float* hmid,
+                                  float* qh, unsigned* sync, int* steps_dev, hipStream_t s);
 
 #define TRY(expr)            \
   do {                       \
@@ -124,7 +131,9 @@ static int lp_decode_impl(const nast_lp_decode_args* A, float* workspace, int* s
   const bool fused = nast_lp_decode_fused_eligible(A) && (reinterpret_cast<uintptr_t>(A->eos) & 15) == 0;
   hipLaunchKernelGGL(lp_candidates_kernel, dim3(((int64_t)B * NC + 3) / 4), dim3(256), 0, s, A->memory, A->origin_length, A->eos,
                      w.cand, w.mask, B, S1, d);
-  if (!fused)
+  // one persistent launch of 8 clusters x 32 workgroups with cluster barriers between the operations (decode_cluster.hip)
+  const bool cluster = !fused && nast_lp_decode_cluster_eligible(A);
+  if (!fused && !cluster)
     hipLaunchKernelGGL(lp_init_kernel, dim3(B), dim3(256), 0, s, A->memory, A->pos_w, w.x, w.now_pos, A->allpos, B, S1, d, L + 1);
   NAST_CHECK_LAUNCH("nast_lp_decode_f32(init)");
   {   // wk(candidates), wk(unk), cross-attention K/V of every layer: grouped launches
@@ -144,8 +153,10 @@ static int lp_decode_impl(const nast_lp_decode_args* A, float* workspace, int* s
       }
     }
   }
-  if (fused) {
-    TRY(nast_lp_decode_fused_launch(A, w.cand, w.KC, w.kunk, w.mk, w.mv, w.kc, w.vc, early_exit ? w.done : nullptr, s));
+  if (fused || cluster) {
+    if (fused) TRY(nast_lp_decode_fused_launch(A, w.cand, w.KC, w.kunk, w.mk, w.mv, w.kc, w.vc, early_exit ? w.done : nullptr, s));
+    else TRY(nast_lp_decode_cluster_launch(A, w.cand, w.KC, w.kunk, w.mk, w.mv, w.kc, w.vc, w.x, w.q, w.a, w.x1, w.x2, w.hmid, w.qh, w.sync,
+                                           early_exit ? w.done : nullptr, s));
     int steps = L;
     if (early_exit) {   // the reference's early exit, read off the finished table (one read-back, as the loop's last one)
       if (hipMemcpyAsync(&steps, w.done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {

@@ -449,6 +449,11 @@ __global__ void lp_steps_from_allpos_kernel(const int64_t* __restrict__ allpos, 
 
 }  // namespace
 
+int nast_lp_steps_from_allpos_launch(const int64_t* allpos, const int64_t* olen, int B, int L, int* steps_dev, hipStream_t s) {
+  hipLaunchKernelGGL(lp_steps_from_allpos_kernel, dim3(1), dim3(256), 0, s, allpos, olen, B, L, steps_dev);
+  return 0;
+}
+
 bool nast_lp_decode_fused_eligible(const nast_lp_decode_args* A) {
   const char* e = getenv("NAST_DECODE_FUSED");      // opt-in (see the header); read per call: tests switch it in-process
   if (!e || atoi(e) == 0) return false;

@@ -1,5 +1,5 @@
-"""GPU time of the skip decode alone (nast_lp_decode_f32, all L steps, no read-backs): the one-kernel path of decode_fused.hip
-against the step-by-step path, at 64 and 512 sentences of the bench shape.   python tools/decode_bench.py [B ...]"""
+"""GPU time of the skip decode alone (nast_lp_decode_f32, all L steps, no read-backs): the cluster kernel of decode_cluster.hip
+(and, with DECODE_BENCH_FUSED=1, the one-workgroup-per-block kernel of decode_fused.hip) against the step-by-step path, at 64 and 512 sentences of the bench shape.   python tools/decode_bench.py [B ...]"""
 import os
 import sys
 
@@ -21,8 +21,11 @@ for B in Bs:
     lengths = torch.randint(4, S + 1, (B,)).cuda()
     eos, unk = torch.randn(d).cuda(), torch.randn(d).cuda()
     buf = torch.zeros(B, L + 1, dtype=torch.long, device="cuda")
-    for mode in ("0", "1"):
-        os.environ["NAST_DECODE_FUSED"] = mode
+    for mode in ("step", "fused", "cluster"):
+        if mode == "fused" and os.environ.get("DECODE_BENCH_FUSED", "0") == "0":
+            continue
+        os.environ["NAST_DECODE_FUSED"] = "1" if mode == "fused" else "0"
+        os.environ["NAST_DECODE_CLUSTER"] = "1" if mode == "cluster" else "0"
         with torch.no_grad(), ops.async_decode(None):
             for _ in range(2):
                 lp._native_decode(memory, lengths, eos, unk, buf)
@@ -33,4 +36,4 @@ for B in Bs:
                 lp._native_decode(memory, lengths, eos, unk, buf)
             e1.record()
             torch.cuda.synchronize()
-        print(f"B={B} fused={mode}: {e0.elapsed_time(e1) / 5:.3f} ms per decode", flush=True)
+        print(f"B={B} {mode}: {e0.elapsed_time(e1) / 5:.3f} ms per decode", flush=True)
