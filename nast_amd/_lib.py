@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnast_hip.so")
+LIB_PATH = os.environ.get("NAST_HIP_LIB") or os.path.join(_HERE, "lib", "libnast_hip.so")   # (override: lab builds, tools/*_stamps*)
 
 GEMM_MAX_GROUP = 8
 GEMM_MAX_SRC = 3

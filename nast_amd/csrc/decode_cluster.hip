@@ -40,6 +40,12 @@ constexpr int MAXOPS = 8 * 4 + 2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef CLUSTER_STAMPS   // debug build only (tools/cluster_stamps.sh): where the time of a decode goes, summed per phase, for 2 workgroups
+__device__ long long g_cluster_dbg[2][8];
+#define TS(i) do { const long long tn_ = wall_clock64(); tacc[i] += tn_ - tlast; tlast = tn_; } while (0)
+#else
+#define TS(i) do { } while (0)
+#endif
 __device__ unsigned g_cluster_err;       // sticky: a barrier poll timed out (some workgroup of the grid was not resident)
 
 struct ClusterArgs {
@@ -98,12 +104,27 @@ __device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t byte
 // stay live through the operations in between (the attention holds 36 keys per lane in registers)
 __device__ __forceinline__ void kill4(float4& v) { asm volatile("" : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)); }
 __device__ __forceinline__ float pick4(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
+// Sums over lane groups without the LDS crossbar (ds_bpermute, what __shfl_xor compiles to): DPP butterflies inside a row of
+// 16 lanes (quad_perm xor 1, xor 2; then row_half_mirror and row_mirror, which pair equal-valued quads / halves), v_readlane
+// across the four rows.  Every lane of the group gets the sum.  (5.9 -> 5.5 ms per decode at 512 sentences.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+  v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);     // row_half_mirror
+  v = dpp_add<0x140>(v);     // row_mirror
   return v;
+}
+__device__ __forceinline__ float wave64_sum(float v) {
+  v = group16_sum(v);
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
 }
 
 __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const ClusterArgs A) {
@@ -259,7 +280,12 @@ __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const Cl
     return abort_s == 0;
   };
 
+#ifdef CLUSTER_STAMPS
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = wall_clock64();
+#endif
   if (!barrier(0)) return;
+  TS(0);
 
   for (int k = 0; k < L; ++k) {
     for (int oi = 0; oi < nops; ++oi) {
@@ -321,6 +347,7 @@ __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const Cl
               if (nchunk > 1 || g == 0) {
                 if (g > 0 || ch > 0) __syncthreads();    // every wave has read the previous image
                 store_a();
+                TS(1);
                 if (has_ln && ch == 0) { ln_s[tid] = ln_g1; ln_s[CD + tid] = ln_b1; }
                 if (ch + 1 < nchunk) load_a(ch + 1);     // in flight during this chunk's MFMAs
                 else if (nchunk > 1 && TG * (g + 1) < nmine) load_a(0);
@@ -354,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const Cl
                     }
                   }
                   __syncthreads();
+                  TS(2);
                 }
               }
               // MFMA: lane (lr, lg) of wave w feeds k = 64 w + 16 lg + 4 i + s, the same for A and W
@@ -380,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const Cl
                 }
               }
             }
+            TS(3);
             // ---- K-split reduction through LDS + epilogue, tile by tile ----
 #pragma unroll
             for (int u = 0; u < TG; ++u) {
@@ -412,6 +441,7 @@ __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const Cl
             }
           }
         }
+        TS(4);
       } else if (type == OP_ATTN) {
         // scaled_attention (transformer.py:296-303), one query per sentence and head: lane l owns dims 4l..4l+3 (head l / 16)
         const int self = uni(o.self), sstride = uni(o.sent_stride);
@@ -477,6 +507,7 @@ __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const Cl
           const float inv = 1.f / sum;
           st16_sc1(rs_o, (uint32_t)(b * CD + 4 * lane) * 4u, make_float4(ov.x * inv, ov.y * inv, ov.z * inv, ov.w * inv));
         }
+        TS(5);
       } else {
         // ---- skip decision (:543-567) and the next input (:535-541), one wavefront per sentence ----
         const __amdgpu_buffer_rsrc_t rs_qh = rsrc_of(A.qh);
@@ -489,9 +520,9 @@ __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const Cl
           const float4 q4 = ld16_sc1(rs_qh, (uint32_t)(b * CD + 4 * lane) * 4u);
           const float4 g4 = *reinterpret_cast<const float4*>(A.norm_w + 4 * lane);
           const float4 n4 = *reinterpret_cast<const float4*>(A.norm_b + 4 * lane);
-          const float mu = wave_sum(x4.x + x4.y + x4.z + x4.w) * (1.f / CD);
+          const float mu = wave64_sum(x4.x + x4.y + x4.z + x4.w) * (1.f / CD);
           const float4 cx = make_float4(x4.x - mu, x4.y - mu, x4.z - mu, x4.w - mu);
-          const float rs = rsqrtf(wave_sum(cx.x * cx.x + cx.y * cx.y + cx.z * cx.z + cx.w * cx.w) * (1.f / CD) + 1e-6f);
+          const float rs = rsqrtf(wave64_sum(cx.x * cx.x + cx.y * cx.y + cx.z * cx.z + cx.w * cx.w) * (1.f / CD) + 1e-6f);
           const float4 h4 = make_float4(cx.x * rs * g4.x + n4.x, cx.y * rs * g4.y + n4.y, cx.z * rs * g4.z + n4.z, cx.w * rs * g4.w + n4.w);
           float logit[4];
 #pragma unroll
@@ -499,8 +530,8 @@ __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const Cl
             const float* kr = j == 0 ? A.kunk : A.KC + ((size_t)b * NC + now + j) * CD;
             const float4 k4 = *reinterpret_cast<const float4*>(kr + 4 * lane);
             const float4 l4 = *reinterpret_cast<const float4*>(A.lin_w + j * CD + 4 * lane);
-            const float dq = wave_sum(q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w);
-            const float dl = wave_sum(h4.x * l4.x + h4.y * l4.y + h4.z * l4.z + h4.w * l4.w);
+            const float dq = wave64_sum(q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w);
+            const float dl = wave64_sum(h4.x * l4.x + h4.y * l4.y + h4.z * l4.z + h4.w * l4.w);
             logit[j] = dq / 16.f + (dl + A.lin_b[j]);                                  // / sqrt(d_model), :551-552
           }
           if (k == 0) {                                                                // :553-555
@@ -543,10 +574,16 @@ __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const Cl
           }
         }
       }
+      if (type == OP_STEP) TS(6);
       if (k == L - 1 && oi == nops - 1) break;           // nothing follows: no one waits for this workgroup's last stores
       if (!barrier(oi + 1 == nops ? 0 : oi + 1)) return;
+      TS(0);
     }
   }
+#ifdef CLUSTER_STAMPS
+  if (tid == 0 && c == 0 && (m == 0 || m == NMEMBER - 1))
+    for (int i = 0; i < 8; ++i) g_cluster_dbg[m == 0 ? 0 : 1][i] = tacc[i];
+#endif
 }
 
 }  // namespace
@@ -601,6 +638,16 @@ int nast_lp_decode_cluster_launch(const nast_lp_decode_args* A, const float* can
   }
   hipLaunchKernelGGL(nast_lp_decode_cluster_kernel, dim3(NCLUSTER * NMEMBER), dim3(256), 0, s, F);
   if (steps_dev && nast_lp_steps_from_allpos_launch(A->allpos, A->origin_length, A->B, A->L, steps_dev, s) != 0) return NAST_ELAUNCH;
+#ifdef CLUSTER_STAMPS
+  {
+    long long h[2][8];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cluster_dbg), sizeof(h));
+    for (int w = 0; w < 2; ++w)
+      fprintf(stderr, "[cluster stamps, us, member %d] barrier %.0f  A-load %.0f  LN %.0f  MFMA %.0f  reduce+epilogue %.0f  attention %.0f  step %.0f\n",
+              w == 0 ? 0 : NMEMBER - 1, h[w][0] / 100.0, h[w][1] / 100.0, h[w][2] / 100.0, h[w][3] / 100.0, h[w][4] / 100.0, h[w][5] / 100.0, h[w][6] / 100.0);
+  }
+#endif
   NAST_CHECK_LAUNCH("nast_lp_decode_f32(cluster)");
   return NAST_OK;
 }
