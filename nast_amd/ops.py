@@ -551,6 +551,20 @@ def check_packed():
             raise _lib.NastHipError("PackedSeq: the host-side row total disagrees with the device lengths")
 
 
+def check_decode():
+    """Raise if a cluster skip decode (csrc/decode_cluster.hip) gave up at one of its barriers since the library was loaded:
+    some workgroup of its grid was not resident (a CU mask, a partitioned device), the positions of that call are garbage.
+    NAST_DECODE_CLUSTER=0 selects the step-by-step path.  One synchronous 4-byte read: called where the steps synchronise."""
+    if not torch.cuda.is_available():
+        return
+    import ctypes as C
+    st = C.c_int(0)
+    call("nast_lp_decode_cluster_status", C.byref(st))
+    if st.value:
+        raise _lib.NastHipError("nast_lp_decode_f32: a cluster decode timed out at a barrier (grid not resident); "
+                                "set NAST_DECODE_CLUSTER=0 for the step-by-step path")
+
+
 class PackedSeq:
     ROW_MULTIPLE = 64        # packed buffers are padded to a multiple of this (weight-gradient GEMMs: K = rows, K % 32 == 0
     #                          keeps them on the fast path).  Padding rows duplicate row 0 on the way in, are kept finite in

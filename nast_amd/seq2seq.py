@@ -281,6 +281,7 @@ class Seq2seq(BaseModel):
         with ops.packed_rows(self.pack_rows and incoming.data.sent.numel() >= self.pack_min_tokens):
             out = self._f_step(incoming, temperature, cyc_rec_enable, use_inference_z=use_inference_z)
             ops.check_packed()       # (the step has just synchronised for its loss values)
+            ops.check_decode()
             return tuple(item(x) for x in out)
 
     def d_step(self, incoming, temperature, *, use_inference_z):
@@ -293,6 +294,7 @@ class Seq2seq(BaseModel):
         with ops.packed_rows(self.pack_rows and incoming.data.sent.numel() >= self.pack_min_tokens):
             out = self._d_step(incoming, temperature, use_inference_z=use_inference_z)
             ops.check_packed()
+            ops.check_decode()
             return out.item()
 
     def _f_step(self, incoming, temperature, cyc_rec_enable=True, *, use_inference_z, capturing=False):
