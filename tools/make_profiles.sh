@@ -5,16 +5,16 @@ R=${1:-r2}          # round tag: profiles/<tag>_*  from gpurun_out/{bench_<tag>_
 RN=${R#r}
 cd "$(dirname "$0")/.."
 { echo "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-also   (round ${RN}, MI355X, 512 sentences/GPU)"
-  echo "# whole run = 5 warm-up + 20 timed (two-stream overlap) + 5 roofline steps (overlap off) = 30 steps; 'per step' figures divide by 30."
+  echo "# whole run = 5 warm-up + 20 timed (two-stream overlap) + 5 roofline steps (overlap off) ; 'per step' figures divide by the number of f_steps in the run (= launches of the NoiseLayer kernel)."
   echo "# Kernels of the two streams run concurrently in 25 of the 30 steps, so per-kernel durations here are longer than a kernel alone;"
   echo "# the un-overlapped durations that bench.py's roofline block measures are in ${R}_bench_kernel_stats_no_overlap.txt"
   echo "# bench line of the profiled run:"; grep "^{" gpurun_out/prof_${R}.log; echo
-  python tools/prof_summary.py gpurun_out/prof_${R} 30 40; } > profiles/${R}_bench_kernel_stats.txt
+  python tools/prof_summary.py gpurun_out/prof_${R} 0 40; } > profiles/${R}_bench_kernel_stats.txt
 { echo "# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-also --no-overlap   (round ${RN}, MI355X, 512 sentences/GPU)"
-  echo "# 30 steps, single stream: every kernel runs alone, durations comparable with roofline.avg_launch_us of the bench line"
+  echo "# single stream: every kernel runs alone, durations comparable with roofline.avg_launch_us of the bench line"
   echo "# bench line of the profiled run:"; grep "^{" gpurun_out/prof_${R}_noov.log; echo
-  python tools/prof_summary.py gpurun_out/prof_${R}_noov 30 40; echo
-  echo "# GEMM launches grouped by workgroup count"; python tools/trace_groups.py gpurun_out/prof_${R}_noov 30 nast_gemm 25; } > profiles/${R}_bench_kernel_stats_no_overlap.txt
+  python tools/prof_summary.py gpurun_out/prof_${R}_noov 0 40; echo
+  echo "# GEMM launches grouped by workgroup count"; python tools/trace_groups.py gpurun_out/prof_${R}_noov 0 nast_gemm 25; } > profiles/${R}_bench_kernel_stats_no_overlap.txt
 cp gpurun_out/prof_${R}/p_kernel_stats.csv profiles/${R}_bench_kernel_stats.csv
 cp gpurun_out/prof_${R}_noov/p_kernel_stats.csv profiles/${R}_bench_kernel_stats_no_overlap.csv
 grep "^{" gpurun_out/bench_${R}_default.log > profiles/${R}_bench_line.json

@@ -5,7 +5,10 @@ pat = sys.argv[3] if len(sys.argv) > 3 else ''
 topn = int(sys.argv[4]) if len(sys.argv) > 4 else 30
 f = (glob.glob(d + '/*kernel_trace.csv') + glob.glob(d + '/*/*kernel_trace.csv'))[0]
 agg = collections.defaultdict(lambda: [0, 0.0])
-for r in csv.DictReader(open(f)):
+trace = list(csv.DictReader(open(f)))
+if steps <= 0:      # 0 = count the steps: the NoiseLayer kernel runs once per f_step
+    steps = float(sum(1 for r in trace if 'nast_noise_kernel' in r['Kernel_Name']) or 1)
+for r in trace:
     if pat not in r['Kernel_Name']: continue
     name = r['Kernel_Name'].split('(')[0][-34:]
     key = (name, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']))
