@@ -352,8 +352,9 @@ class MatmulNNFn(torch.autograd.Function):
     """y[M,N] = x[M,K] @ E[K,N]   (soft tokens x embedding table, transformer.py:229, :403)"""
 
     @staticmethod
-    def forward(ctx, x, E):
+    def forward(ctx, x, E, holder=None):
         _chk(x, E)
+        ctx.holder = holder          # SharedKVFn holder of x: its consumers' gradients meet in one buffer (see PackedSoft)
         x2 = _c(x).view(-1, x.shape[-1])
         E0 = E
         E = _c(E)
@@ -374,19 +375,26 @@ class MatmulNNFn(torch.autograd.Function):
         dy2 = _c(dy).view(M, N)
         descs, dx2 = [], None
         if ctx.needs_input_grad[0]:
-            dx2 = torch.empty_like(x2)                       # dX = dY E^T
-            descs.append(desc(dy2, E, dx2, M, K, N, N, N, K, 0, 1))
+            hold = ctx.holder
+            if hold is None:
+                dx2 = torch.empty_like(x2)                       # dX = dY E^T
+                descs.append(desc(dy2, E, dx2, M, K, N, N, N, K, 0, 1))
+            elif hold.buf is None:                               # first consumer to run backward: plain store
+                hold.buf = torch.empty_like(x2)
+                descs.append(desc(dy2, E, hold.buf, M, K, N, N, N, K, 0, 1))
+            else:                                                # the others add in the GEMM epilogue
+                descs.append(desc(dy2, E, hold.buf.view(M, K), M, K, N, N, N, K, 0, 1, flags=GEMM_ACCUM))
         (dE,), (rE,) = grad_buffers(list(ctx.params))
         if dE is not None:                                   # dE += X^T dY
             descs.append(desc(x2, dy2, dE, K, N, M, K, N, N, 1, 0, flags=GEMM_ATOMIC))
         if descs:
             gemm(descs)
         grads_written(ctx.params)
-        return (dx2.view(ctx.xshape) if dx2 is not None else None), rE
+        return (dx2.view(ctx.xshape) if dx2 is not None else None), rE, None
 
 
-def matmul_nn(x, E):
-    return MatmulNNFn.apply(x, E)
+def matmul_nn(x, E, holder=None):
+    return MatmulNNFn.apply(x, E, holder)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -629,7 +637,9 @@ class PackedSoft:
     consumers take the rows through `soft_embed` (x @ table on real rows only) and `column` (one vocabulary column)."""
 
     def __init__(self, rows, ps):
-        self.rows, self.ps = rows, ps
+        # the rows feed two embedding tables (the generator's cycle pass and the discriminator, seq2seq.py:492-519): their
+        # [rows, V] gradients meet in one buffer instead of a 350-MB autograd add (SharedKVFn)
+        self.rows, self.ps = shared_kv(rows), ps
         self.shape = (ps.B, ps.width, rows.shape[-1])
         self.device, self.is_cuda = rows.device, rows.is_cuda
 
@@ -641,7 +651,7 @@ class PackedSoft:
 
     def soft_embed(self, table):
         """[B, T, d] = soft tokens @ table (zeros at the padded positions)"""
-        return unpack_rows(matmul_nn(self.rows, table), self.ps)
+        return unpack_rows(matmul_nn(self.rows, table, getattr(self.rows, "nast_kv_holder", None)), self.ps)
 
     def column(self, j):
         """[B, T] weights of vocabulary entry j (no gradient), zeros at the padded positions"""
