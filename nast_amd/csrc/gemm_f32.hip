@@ -427,13 +427,9 @@ __device__ __forceinline__ void gemm_tile(const nast_gemm_desc& D, int tm, int t
     }
 }
 
-template <int BM, int BN, int BK, bool FAST, bool BF16>
-__global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) {
-  using GA = TileGeom<BM, BK>;
-  using GB = TileGeom<BN, BK>;
-  GEMM_STAMP(0);
-  __shared__ __attribute__((aligned(16))) float smem[2 * (GA::SZ + GB::SZ)];
-  // ---- which problem / tile / k-slice ----
+// which problem / output tile / K slice a workgroup takes (shared by the tile kernels)
+struct TileCoord { int gi, tm, tn, kz; };
+__device__ __forceinline__ TileCoord decode_tile(const GemmLaunch& P) {
   // Optional XCD-contiguous order (NAST_GEMM_XCD=1): workgroups are dealt round-robin over the 8 XCDs, so making the
   // logical tile index contiguous per XCD lets the N/BN tiles that re-read one A row panel share an L2.  Measured:
   // +1..8 % on single-problem launches in tools/gemm_bench, but -7 % on the whole step (74.5 -> 80.4 ms): in the
@@ -446,7 +442,6 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
   }
   int gi = 0;
   while (gi + 1 < P.count && bid >= P.tile_start[gi + 1]) ++gi;
-  const nast_gemm_desc& D = P.d[gi];
   int local = bid - P.tile_start[gi];
   // Per-problem XCD swizzle (NAST_GEMM_XCD=3): inside chunks of 8 * tiles_n consecutive workgroups, the tiles_n tiles of one
   // A row panel go to the workgroups of ONE XCD (blockIdx % 8) instead of one tile to each XCD, so the panel is fetched
@@ -460,10 +455,24 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
       if ((c + 1) * C <= P.tile_start[gi + 1] - sa) local = (sa - s0) + c * C + (r & 7) * (C >> 3) + (r >> 3);
     }
   }
-  const int tn = local % P.tiles_n[gi];
+  TileCoord t;
+  t.gi = gi;
+  t.tn = local % P.tiles_n[gi];
   const int tq = local / P.tiles_n[gi];
-  const int tm = tq % P.tiles_m[gi];
-  const int kz = tq / P.tiles_m[gi];
+  t.tm = tq % P.tiles_m[gi];
+  t.kz = tq / P.tiles_m[gi];
+  return t;
+}
+
+template <int BM, int BN, int BK, bool FAST, bool BF16>
+__global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) {
+  using GA = TileGeom<BM, BK>;
+  using GB = TileGeom<BN, BK>;
+  GEMM_STAMP(0);
+  __shared__ __attribute__((aligned(16))) float smem[2 * (GA::SZ + GB::SZ)];
+  const TileCoord tc = decode_tile(P);
+  const int gi = tc.gi, tm = tc.tm, tn = tc.tn, kz = tc.kz;
+  const nast_gemm_desc& D = P.d[gi];
   const int per = P.kt_per_split[gi];
   const bool a_kc = (D.transA == 0), b_kc = (D.transB != 0);
   if (a_kc && b_kc) gemm_tile<BM, BN, BK, true, true, FAST, BF16>(D, tm, tn, kz, per, smem);          // y = x W^T
@@ -471,6 +480,20 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_kernel(const GemmLaunch P) 
   else if (!a_kc && !b_kc) gemm_tile<BM, BN, BK, false, false, FAST, BF16>(D, tm, tn, kz, per, smem); // dW = dy^T x
   else gemm_tile<BM, BN, BK, false, true, FAST, BF16>(D, tm, tn, kz, per, smem);
   GEMM_STAMP(5);
+}
+
+#include "gemm_bf16_tile.h"
+
+__global__ __launch_bounds__(256, 2) void nast_gemm_bf16_kernel(const GemmLaunch P) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[bf16tile::SMEM];
+  const TileCoord tc = decode_tile(P);
+  const nast_gemm_desc& D = P.d[tc.gi];
+  const int per = P.kt_per_split[tc.gi];
+  const bool a_kc = (D.transA == 0), b_kc = (D.transB != 0);
+  if (a_kc && b_kc) bf16tile::gemm_tile<true, true>(D, tc.tm, tc.tn, tc.kz, per, smem);
+  else if (a_kc && !b_kc) bf16tile::gemm_tile<true, false>(D, tc.tm, tc.tn, tc.kz, per, smem);
+  else if (!a_kc && !b_kc) bf16tile::gemm_tile<false, false>(D, tc.tm, tc.tn, tc.kz, per, smem);
+  else bf16tile::gemm_tile<false, true>(D, tc.tm, tc.tn, tc.kz, per, smem);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -665,7 +688,7 @@ static bool fast_ok(const nast_gemm_desc* descs, int count) {
   return true;
 }
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, bool BF16TILE = false>
 static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t stream, bool dry, int* total_tiles) {
   GemmLaunch P;
   P.count = count;
@@ -804,6 +827,10 @@ static int plan_and_launch(const nast_gemm_desc* descs, int count, hipStream_t s
   if (start == 0) return 0;
   bool bf16 = true;
   for (int i = 0; i < count; ++i) bf16 = bf16 && (descs[i].flags & NAST_GEMM_BF16);
+  if constexpr (BF16TILE) {   // the caller has checked fast_ok<128, 128, 64> and that every member asks for bf16
+    hipLaunchKernelGGL(nast_gemm_bf16_kernel, dim3(start), dim3(256), 0, stream, P);
+    return 0;
+  }
   if (fast_ok<BM, BN, BK>(descs, count)) {
     if (bf16) hipLaunchKernelGGL((nast_gemm_f32_kernel<BM, BN, BK, true, true>), dim3(start), dim3(256), 0, stream, P);
     else hipLaunchKernelGGL((nast_gemm_f32_kernel<BM, BN, BK, true, false>), dim3(start), dim3(256), 0, stream, P);
@@ -893,7 +920,9 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
     for (int i = 0; i < nrest; ++i) all_bf16 = all_bf16 && (rest[i].flags & NAST_GEMM_BF16);
     int cfg = tilesL >= (all_bf16 ? std::min(t128_min, 128) : t128_min) ? 2 : 0;
     if (force >= 0) cfg = force;
-    if (cfg == 2) plan_and_launch<128, 128, NAST_BK128>(rest, nrest, stream, false, nullptr);
+    static const bool bf16_tile_on = [] { const char* e = getenv("NAST_GEMM_BF16_TILE"); return e ? atoi(e) != 0 : true; }();   // tuning aid: 0 = the fp32-image variant
+    if (cfg == 2 && all_bf16 && bf16_tile_on && fast_ok<128, 128, 64>(rest, nrest)) plan_and_launch<128, 128, 64, true>(rest, nrest, stream, false, nullptr);
+    else if (cfg == 2) plan_and_launch<128, 128, NAST_BK128>(rest, nrest, stream, false, nullptr);
     else plan_and_launch<64, 64, 32>(rest, nrest, stream, false, nullptr);
     if (nast_prof_shapes(1)) nast_prof_after(1, stream, flops_of(rest, nrest), signature(cfg == 2 ? "t128" : "t64", rest, nrest).c_str());
     else nast_prof_after(1, stream, flops_of(rest, nrest));

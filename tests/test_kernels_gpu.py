@@ -425,7 +425,8 @@ def test_generator_nll_fused(ops, rows, d, V, temp):
     relclose(out, ref); relclose(gx.grad, rx.grad); relclose(gW.grad, rW.grad); relclose(gb.grad, rb.grad)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 64, 64), (1088, 256, 256), (300, 1024, 256), (2112, 9600, 256)])
+@pytest.mark.parametrize("M,N,K", [(128, 64, 64), (1088, 256, 256), (300, 1024, 256), (2112, 9600, 256), (4164, 1024, 1024), (2052, 2048, 96),
+                                   (16388, 256, 1024)])
 def test_gemm_bf16_variant(ops, M, N, K):
     """bf16-MFMA variant of the grouped GEMM (fp32 storage, fp32 accumulate): forward, dgrad, wgrad, bias grad within the
     bf16 tolerance of north_star (2e-2 relative to the largest element)."""
@@ -446,6 +447,44 @@ def test_gemm_bf16_variant(ops, M, N, K):
     if M > 1024:      # (M <= 1024 forward goes through the small-M kernel, which is fp32 only)
         assert (y32 - y).abs().max().item() > 0
     relclose(y32, ref, 1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(4160, 1024, 256), (2112, 2048, 512)])
+def test_gemm_bf16_tile_epilogues(ops, M, N, K, monkeypatch):
+    """The bf16 tile kernel (csrc/gemm_bf16_tile.h: bf16 K-contiguous LDS images, 128 x 128 x 64) through the epilogues the model
+    uses -- bias + ReLU with the ReLU mask in the backward (FFN), bias + residual, soft tokens x table (n-contiguous B) -- against
+    fp32 torch at north_star's 2e-2, and against the older fp32-image variant (NAST_GEMM_BF16_TILE=0 is read once per process,
+    so the comparison here is with torch only)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    res, R = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    # y = relu(x W^T + b): forward epilogue RELU.  The backward is compared with the device's own gates: a pre-activation
+    # within the bf16 error of zero opens in one arithmetic and not in the other, which is a property of the rounding,
+    # not an error of either product (tests/test_model_gpu.py replays gates for the same reason).
+    ref = torch.relu(torch.nn.functional.linear(x, W, b))
+    gx, gW, gb = (dev(t).requires_grad_(True) for t in (x, W, b))
+    with ops.gemm_precision("bf16"):
+        y = ops.linear(gx, gW, gb, None, True)
+        (y * dev(R)).sum().backward()
+    dy = R * (y.detach().cpu() > 0).float()
+    for a, r in ((y, ref), (gx.grad, dy @ W), (gW.grad, dy.t() @ x), (gb.grad, dy.sum(0))):
+        relclose(a, r, 2e-2)
+    # y = res + x W^T + b
+    with ops.gemm_precision("bf16"):
+        y2 = ops.linear(dev(x), dev(W), dev(b), dev(res))
+    relclose(y2, res + torch.nn.functional.linear(x, W, b), 2e-2)
+    # soft tokens x table: y = p E (E [K', d] n-contiguous), dp = dy E^T, dE = p^T dy
+    p_, E = torch.softmax(torch.randn(M, N, generator=g), -1), torch.randn(N, K, generator=g)
+    rp, rE = p_.clone().requires_grad_(True), E.clone().requires_grad_(True)
+    refm = rp @ rE
+    Rm = torch.randn(M, K, generator=g)
+    (refm * Rm).sum().backward()
+    gp, gE = dev(p_).requires_grad_(True), dev(E).requires_grad_(True)
+    with ops.gemm_precision("bf16"):
+        ym = ops.matmul_nn(gp, gE)
+        (ym * dev(Rm)).sum().backward()
+    for a, r in ((ym, refm), (gp.grad, rp.grad), (gE.grad, rE.grad)):
+        relclose(a, r, 2e-2)
 
 
 def test_step_bf16_variant_vs_oracle():
