@@ -334,7 +334,9 @@ int nast_lp_decode_f32(const nast_lp_decode_args* args, int* steps_out, void* st
  * a message; 64 MiB covers 128 sentences at S1 = 33, d = 256, L = 32, 3 layers.  The call makes no hipMalloc / hipFree and no
  * other allocation.  Every call on a GPU shares that GPU's buffer (it keeps the last call's contents; every word a
  * kernel reads is rewritten by the call itself first): calls that overlap on one GPU -- two streams, two threads -- RACE;
- * serialise them, or use nast_lp_decode_f32 with one workspace per concurrent call. */
+ * serialise them, or use nast_lp_decode_f32 with one workspace per concurrent call.
+ * Under HIP graph capture pass *steps_out < 0: with *steps_out >= 0 the call reads the progress back (hipMemcpyAsync to
+ * host memory + hipStreamSynchronize), which a capturing stream does not allow -- the call then returns NAST_EINVAL. */
 #define NAST_LP_DECODE_STATIC_BYTES (64u << 20)
 int nast_lp_decode_static_f32(const nast_lp_decode_args* args, int* steps_out, void* stream);
 

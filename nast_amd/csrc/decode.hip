@@ -1,6 +1,8 @@
 // Greedy skip decoding of the LengthPredictor (transformer.py:525-570) driven from native code: ~26 kernel
 // launches per step are enqueued back to back from C++ (no interpreter in the loop), with a real K/V cache
 // instead of the reference's per-step re-projection of the whole prefix.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -261,7 +263,7 @@ extern "C" int nast_lp_decode_f32(const nast_lp_decode_args* A, int* steps_out, 
 // at its own address until the process ends; the address is looked up once per device with hipGetSymbolAddress and kept.
 #define NAST_LP_DECODE_STATIC_MAX_DEVICES 64
 static __device__ __align__(256) unsigned char scratch[NAST_LP_DECODE_STATIC_BYTES];
-static void* g_scratch_ptr[NAST_LP_DECODE_STATIC_MAX_DEVICES];      // per device; nullptr = not looked up yet
+static std::atomic<void*> g_scratch_ptr[NAST_LP_DECODE_STATIC_MAX_DEVICES];      // per device; nullptr = not looked up yet (two threads may both look it up: same value)
 
 extern "C" int nast_lp_decode_static_f32(const nast_lp_decode_args* A, int* steps_out, void* stream_) {
   NAST_REQUIRE(A && steps_out, "nast_lp_decode_static_f32: NULL args");
@@ -272,19 +274,28 @@ extern "C" int nast_lp_decode_static_f32(const nast_lp_decode_args* A, int* step
                "nast_lp_decode_static_f32: this decode needs %lld bytes of workspace, the built-in buffer holds %lld "
                "(B=%d S1=%d d=%d L=%d layers=%d): use nast_lp_decode_f32 with a caller workspace",
                (long long)need, (long long)NAST_LP_DECODE_STATIC_BYTES, A->B, A->S1, A->d, A->L, A->nlayers);
+  if (*steps_out >= 0) {     // the early-exit read-backs synchronise the stream: not allowed while it is being captured
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream_, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      nast_set_error("nast_lp_decode_static_f32: the stream is being captured; pass *steps_out < 0 (no read-back of the progress)");
+      return NAST_EINVAL;
+    }
+  }
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NAST_LP_DECODE_STATIC_MAX_DEVICES) {
     nast_set_error("nast_lp_decode_static_f32: hipGetDevice failed or device index %d out of range", dev);
     return NAST_ELAUNCH;
   }
-  if (g_scratch_ptr[dev] == nullptr) {      // first call on this device (which is current): its copy of the array
+  void* sp = g_scratch_ptr[dev].load(std::memory_order_relaxed);
+  if (sp == nullptr) {      // first call on this device (which is current): its copy of the array
     void* ptr = nullptr;
     const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess || ptr == nullptr) {
       nast_set_error("nast_lp_decode_static_f32: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
       return NAST_ELAUNCH;
     }
-    g_scratch_ptr[dev] = ptr;
+    g_scratch_ptr[dev].store(ptr, std::memory_order_relaxed);
+    sp = ptr;
   }
-  return lp_decode_impl(A, reinterpret_cast<float*>(g_scratch_ptr[dev]), steps_out, (hipStream_t)stream_);
+  return lp_decode_impl(A, reinterpret_cast<float*>(sp), steps_out, (hipStream_t)stream_);
 }

@@ -29,6 +29,14 @@ class _Entry:
     __slots__ = ("seen", "graph", "out", "sent", "length", "domain", "incoming")
 
 
+def _hyper(opt):
+    """The optimizer's hyper-parameters travel to nast_multi_adam_f32 as host scalars, i.e. a captured step holds them as
+    constants: they are part of the key, so a changed lr / betas / eps / weight decay (a schedule, a restore()) captures a
+    new graph instead of silently replaying the old values."""
+    return tuple((float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+                 for g in opt.param_groups)
+
+
 class StepGraphs:
     WARM = 2
     MAX_KEYS = 16        # a temperature schedule that changes every step never repeats a key: such keys stay eager and are dropped
@@ -114,12 +122,12 @@ class StepGraphs:
 
     def f_step(self, incoming, temperature, cyc_rec_enable, use_inference_z):
         tr = self.tr
-        key = ("f", incoming.data.sent.shape[0], float(temperature), bool(cyc_rec_enable), bool(use_inference_z))
+        key = ("f", incoming.data.sent.shape[0], float(temperature), bool(cyc_rec_enable), bool(use_inference_z)) + _hyper(tr.optimizer_F)
         return self._run(key, incoming, tr.optimizer_F,
                          lambda inc, cap: tr._f_step(inc, temperature, cyc_rec_enable, use_inference_z=use_inference_z, capturing=cap))
 
     def d_step(self, incoming, temperature, use_inference_z):
         tr = self.tr
-        key = ("d", incoming.data.sent.shape[0], float(temperature), bool(use_inference_z))
+        key = ("d", incoming.data.sent.shape[0], float(temperature), bool(use_inference_z)) + _hyper(tr.optimizer_D)
         return self._run(key, incoming, tr.optimizer_D,
                          lambda inc, cap: (tr._d_step(inc, temperature, use_inference_z=use_inference_z, capturing=cap),))[0]
