@@ -636,7 +636,10 @@ class PackedSoft:
     T_b = ps.len positions at rows ps.off[b]...  Quacks like the [B, T, V] tensor for the shape queries the model makes;
     consumers take the rows through `soft_embed` (x @ table on real rows only) and `column` (one vocabulary column)."""
 
-    def __init__(self, rows, ps):
+    def __init__(self, rows, ps, unnormalised=False):
+        # unnormalised: the rows are generator logits, not log-probabilities (GeneratorFn normalise=False): only a consumer
+        # that is invariant under a shift of the row may read them as they are (Seq2seq._approx_packed)
+        self.unnormalised = unnormalised
         # the rows feed two embedding tables (the generator's cycle pass and the discriminator, seq2seq.py:492-519): their
         # [rows, V] gradients meet in one buffer instead of a 350-MB autograd add (SharedKVFn)
         self.rows, self.ps = shared_kv(rows), ps
@@ -954,18 +957,25 @@ def ffn_sublayer(x, ln, ffn):
 # generator / softmax family
 # ------------------------------------------------------------------------------------------------
 class GeneratorFn(torch.autograd.Function):
-    """log_softmax((x W^T + b) / temperature)   (Generator.forward, transformer.py:213-214)"""
+    """log_softmax((x W^T + b) / temperature)   (Generator.forward, transformer.py:213-214).
+    normalise=False (temperature 1 only): the logits themselves.  For a consumer that is invariant under a shift of the row
+    -- the Gumbel-softmax, softmax((log_probs + g) / tau) = softmax((logits + g) / tau) -- the log-sum-exp pass over
+    [rows, V] and its backward (the identity on gradients that sum to zero over the row, which a softmax's are) drop out:
+    SURVEY section 8f rank 1, the part of it that pays on this GPU."""
 
     @staticmethod
-    def forward(ctx, x, W, b, temperature):
+    def forward(ctx, x, W, b, temperature, normalise=True):
         _chk(x, W, b)
+        assert normalise or temperature == 1.0
+        ctx.normalise = normalise
         x2 = _c(x).view(-1, x.shape[-1])
         V = W.shape[0]
         y = torch.empty(x2.shape[0], V, device=x.device, dtype=F32)
         gemm([d_fwd(x2, W, y, bias=b)])
         r = Rows(V, 0, 0)
-        call("nast_log_softmax_fwd_f32", _p(y), r, _p(y), r, y.shape[0], V, 1.0 / temperature, _stream())
-        ctx.save_for_backward(x2, W, y)
+        if normalise:
+            call("nast_log_softmax_fwd_f32", _p(y), r, _p(y), r, y.shape[0], V, 1.0 / temperature, _stream())
+        ctx.save_for_backward(x2, W, y if normalise else None)
         ctx.params = live(W, b)
         ctx.it, ctx.xshape = 1.0 / temperature, x.shape
         return y.view(*x.shape[:-1], V)
@@ -975,14 +985,17 @@ class GeneratorFn(torch.autograd.Function):
         x2, W, y = ctx.saved_tensors
         V = W.shape[0]
         gy2 = _c(gy).view(-1, V)
-        gl = torch.empty_like(y)
-        r = Rows(V, 0, 0)
-        call("nast_log_softmax_bwd_f32", _p(gy2), r, _p(y), r, _p(gl), r, y.shape[0], V, ctx.it, _stream())
+        if ctx.normalise:
+            gl = torch.empty_like(y)
+            r = Rows(V, 0, 0)
+            call("nast_log_softmax_bwd_f32", _p(gy2), r, _p(y), r, _p(gl), r, y.shape[0], V, ctx.it, _stream())
+        else:
+            gl = gy2
         (dW, db), (rW, rb) = grad_buffers(list(ctx.params))
         dx = torch.empty_like(x2)
         gemm([d_dgrad([gl], [W], dx)] + wgrad_descs(gl, x2, dW, db))
         grads_written(ctx.params)
-        return dx.view(ctx.xshape), rW, rb, None
+        return dx.view(ctx.xshape), rW, rb, None, None
 
 
 class GeneratorNLLFn(torch.autograd.Function):
@@ -1026,8 +1039,8 @@ def generator_nll(x, W, b, temperature, tokens):
     return GeneratorNLLFn.apply(x, W, b, float(temperature), tokens)
 
 
-def generator(x, W, b, temperature):
-    return GeneratorFn.apply(x, W, b, float(temperature))
+def generator(x, W, b, temperature, normalise=True):
+    return GeneratorFn.apply(x, W, b, float(temperature), bool(normalise))
 
 
 class LogSoftmaxFn(torch.autograd.Function):

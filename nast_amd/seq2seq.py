@@ -245,8 +245,8 @@ class Seq2seq(BaseModel):
                                        e1.reshape(-1, e1.shape[-1]).index_select(0, i1))
                     pad = rows.new_ones(ps.rows - ps.total, rows.shape[-1])
                     G._injected.insert(0, torch.cat((rows, pad), 0))
-            return gumbel_soft_and_index(lp.rows)[0]
-        return self.approx(lp.rows, mode)
+            return gumbel_soft_and_index(lp.rows)[0]     # shift-invariant: logits or log-probs alike (lp.unnormalised)
+        return self.approx(ops.log_softmax(lp.rows) if lp.unnormalised else lp.rows, mode)
 
     def get_lengths(self, tokens, eos_idx):
         """seq2seq.py:545-549: first <eos> index + 1, capped at the width."""

@@ -220,8 +220,8 @@ class Generator(nn.Module):
         super().__init__()
         self.proj = nn.Linear(d_model, vocab_size)
 
-    def forward(self, x, temperature):
-        return ops.generator(x, self.proj.weight, self.proj.bias, temperature)   # transformer.py:213-214
+    def forward(self, x, temperature, normalise=True):
+        return ops.generator(x, self.proj.weight, self.proj.bias, temperature, normalise)   # transformer.py:213-214
 
     def nll(self, x, temperature, tokens):
         """-forward(x, temperature).gather(-1, tokens): the NLLLoss(reduction='none') of seq2seq.py:453 fused in."""
@@ -229,6 +229,8 @@ class Generator(nn.Module):
 
 
 class Decoder(nn.Module):
+    lazy_log_softmax = True     # packed log-probs of the transfer pass leave the generator as logits (see _forward_packed)
+
     def __init__(self, num_layers, d_model, vocab_size, h, dropout):
         super().__init__()
         self.layers = nn.ModuleList([DecoderLayer(d_model, h, dropout) for _ in range(num_layers)])
@@ -274,7 +276,10 @@ class Decoder(nn.Module):
             nll = self.generator.nll(z, temperature, tok).view(-1)[:sub.total]
             return torch.zeros(B * (n - 1), device=x.device, dtype=nll.dtype).index_copy(0, sub.idx, nll).view(B, n - 1)
         if packed_out:                                          # log-probs of the real positions only: [sub.rows, V]
-            return ops.PackedSoft(self.generator(z, temperature), sub)
+            # (at temperature 1 the log-sum-exp pass is left to the consumer: Seq2seq._approx_packed's Gumbel-softmax does
+            # not need it, ops.GeneratorFn)
+            raw = float(temperature) == 1.0 and self.lazy_log_softmax
+            return ops.PackedSoft(self.generator(z, temperature, normalise=not raw), sub, unnormalised=raw)
         return self.generator(ops.unpack_rows(z, sub), temperature)
 
 
