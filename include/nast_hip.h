@@ -153,6 +153,15 @@ int nast_log_softmax_bwd_f32(const float* gy, nast_rows gyr, const float* y, nas
 int nast_nll_gather_f32(const float* y, nast_rows yr, const int64_t* tokens, float* nll, int rows, int V, void* stream);
 int nast_nll_log_softmax_bwd_f32(const float* g, const float* y, nast_rows yr, const int64_t* tokens, float* gx,
                                  nast_rows gxr, int rows, int V, float inv_temp, void* stream);
+/* The same pair WITHOUT the [rows, V] log-probabilities (Generator + NLLLoss, transformer.py:213-214 +
+ * seq2seq.py:453, :504): the forward reads a row of logits once and keeps two floats of it,
+ *   lse[r] = log sum_v exp(x[r, v] * inv_temp);   nll[r] = lse[r] - x[r, tokens[r]] * inv_temp   (nll, tokens may be NULL)
+ * the backward rebuilds the probabilities from the logits:
+ *   gx[r, v] = g[r] * inv_temp * (exp(x[r, v] * inv_temp - lse[r]) - [v == tokens[r]])            (gx may alias x) */
+int nast_lse_nll_f32(const float* x, nast_rows xr, const int64_t* tokens, float* lse, float* nll, int rows, int V,
+                     float inv_temp, void* stream);
+int nast_nll_logits_bwd_f32(const float* g, const float* x, nast_rows xr, const float* lse, const int64_t* tokens, float* gx,
+                            nast_rows gxr, int rows, int V, float inv_temp, void* stream);
 /* Gumbel-softmax sample, utils/gumbel.py:9-69:
  *   g = min(-log(E), 1e10), z = (logits + g) * inv_tau, (mask==0 -> z = -1e9), y = softmax(z), idx = argmax(y)
  * E: the Exp(1) draw (injected noise, parity mode) or NULL -> in-kernel Philox4x32-10 keyed by (seed, offset).

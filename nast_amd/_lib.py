@@ -78,6 +78,8 @@ SIGNATURES = {
     "nast_lp_step_f32": [c_fp] * 16 + [_i] * 6 + [c_fp],
     "nast_nll_gather_f32": [c_fp, Rows, c_fp, c_fp, _i, _i, c_fp],
     "nast_nll_log_softmax_bwd_f32": [c_fp, c_fp, Rows, c_fp, c_fp, Rows, _i, _i, _f, c_fp],
+    "nast_lse_nll_f32": [c_fp, Rows, c_fp, c_fp, c_fp, _i, _i, _f, c_fp],
+    "nast_nll_logits_bwd_f32": [c_fp, c_fp, Rows, c_fp, c_fp, c_fp, Rows, _i, _i, _f, c_fp],
     "nast_lp_logits_fwd_f32": [c_fp] * 5 + [_i] * 4 + [c_fp],
     "nast_lp_logits_bwd_f32": [c_fp] * 8 + [_i] * 4 + [c_fp],
     "nast_lp_decode_workspace_bytes": [_i] * 6,

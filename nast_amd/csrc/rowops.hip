@@ -536,6 +536,95 @@ extern "C" int nast_first_eos_length_i64(const int64_t* tokens, int64_t* lengths
   return NAST_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generator NLL without the [rows, V] log-probabilities: the forward reads a row of logits ONCE
+// and keeps two floats of it -- lse = log sum exp(it * x) and nll = lse - it * x[token] -- the backward rebuilds the
+// probabilities from the logits and lse:  gx = g * it * (exp(it * x - lse) - onehot(token)).
+// One workgroup per row; each thread folds its elements into a running (max, sum) pair (online rescaling), the pairs are
+// combined across the workgroup: one pass for any V.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lse_fold(float& m, float& s, float v) {
+  if (v > m) { s = s * __expf(m - v) + 1.f; m = v; }
+  else s += __expf(v - m);
+}
+__global__ __launch_bounds__(256) void nast_lse_nll_kernel(const float* __restrict__ x, nast_rows xr, const int64_t* __restrict__ tok,
+                                                           float* __restrict__ lse, float* __restrict__ nll, int V, float it) {
+  __shared__ float red_m[4], red_s[4];
+  const int64_t r = blockIdx.x;
+  const float* xp = x + row_offset(r, xr);
+  const RowSpan sp = row_span(V, ptr16(xp));
+  float m = -INFINITY, s = 0.f;
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    const float4 l = reinterpret_cast<const float4*>(xp)[c];
+    lse_fold(m, s, l.x * it); lse_fold(m, s, l.y * it); lse_fold(m, s, l.z * it); lse_fold(m, s, l.w * it);
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) lse_fold(m, s, xp[c] * it);
+  // combine (m, s) pairs: wavefront, then the 4 wavefronts
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mm = fmaxf(m, m2);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mm));
+    m = mm;
+  }
+  if ((threadIdx.x & 63) == 0) { red_m[threadIdx.x >> 6] = m; red_s[threadIdx.x >> 6] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mm = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) ss += red_m[w] == -INFINITY ? 0.f : red_s[w] * __expf(red_m[w] - mm);
+    const float lz = mm + __logf(ss);
+    lse[r] = lz;
+    if (nll) nll[r] = lz - xp[tok[r]] * it;
+  }
+}
+
+__global__ __launch_bounds__(256) void nast_nll_logits_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, nast_rows xr,
+                                                                  const float* __restrict__ lse, const int64_t* __restrict__ tok,
+                                                                  float* __restrict__ gx, nast_rows gxr, int V, float it) {
+  const int64_t r = blockIdx.x;
+  const float* xp = x + row_offset(r, xr);
+  float* op = gx + row_offset(r, gxr);
+  const RowSpan sp = row_span(V, ptr16(xp) && ptr16(op));
+  const float gr = g[r] * it, lz = lse[r];
+  const int t = (int)tok[r];
+  for (int c = threadIdx.x; c < sp.nvec; c += 256) {
+    const float4 l = reinterpret_cast<const float4*>(xp)[c];
+    float4 o;
+    o.x = gr * (__expf(l.x * it - lz) - (4 * c == t ? 1.f : 0.f));
+    o.y = gr * (__expf(l.y * it - lz) - (4 * c + 1 == t ? 1.f : 0.f));
+    o.z = gr * (__expf(l.z * it - lz) - (4 * c + 2 == t ? 1.f : 0.f));
+    o.w = gr * (__expf(l.w * it - lz) - (4 * c + 3 == t ? 1.f : 0.f));
+    reinterpret_cast<float4*>(op)[c] = o;
+  }
+  for (int c = sp.tail0 + threadIdx.x; c < V; c += 256) op[c] = gr * (__expf(xp[c] * it - lz) - (c == t ? 1.f : 0.f));
+}
+
+extern "C" int nast_lse_nll_f32(const float* x, nast_rows xr, const int64_t* tokens, float* lse, float* nll, int rows, int V,
+                                float inv_temp, void* stream) {
+  NAST_REQUIRE(rows >= 0 && V >= 1, "nast_lse_nll_f32: bad sizes");
+  if (rows == 0) return NAST_OK;
+  NAST_REQUIRE(x && lse && (tokens || !nll), "nast_lse_nll_f32: NULL pointer");
+  nast_prof_before(2, (hipStream_t)stream);
+  hipLaunchKernelGGL(nast_lse_nll_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, xr, tokens, lse, nll, V, inv_temp);
+  nast_prof_after(2, (hipStream_t)stream, 4.0 * rows * (double)V);
+  NAST_CHECK_LAUNCH("nast_lse_nll_f32");
+  return NAST_OK;
+}
+
+extern "C" int nast_nll_logits_bwd_f32(const float* g, const float* x, nast_rows xr, const float* lse, const int64_t* tokens, float* gx,
+                                       nast_rows gxr, int rows, int V, float inv_temp, void* stream) {
+  NAST_REQUIRE(rows >= 0 && V >= 1, "nast_nll_logits_bwd_f32: bad sizes");
+  if (rows == 0) return NAST_OK;
+  NAST_REQUIRE(g && x && lse && tokens && gx, "nast_nll_logits_bwd_f32: NULL pointer");
+  nast_prof_before(2, (hipStream_t)stream);
+  hipLaunchKernelGGL(nast_nll_logits_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, g, x, xr, lse, tokens, gx, gxr, V, inv_temp);
+  nast_prof_after(2, (hipStream_t)stream, 8.0 * rows * (double)V);
+  NAST_CHECK_LAUNCH("nast_nll_logits_bwd_f32");
+  return NAST_OK;
+}
+
 extern "C" int nast_nll_gather_f32(const float* y, nast_rows yr, const int64_t* tokens, float* nll, int rows, int V, void* stream) {
   NAST_REQUIRE(rows >= 0 && V >= 1, "nast_nll_gather_f32: bad sizes");
   if (rows == 0) return NAST_OK;

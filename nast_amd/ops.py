@@ -1012,22 +1012,23 @@ class GeneratorNLLFn(torch.autograd.Function):
         y = torch.empty(x2.shape[0], V, device=x.device, dtype=F32)
         gemm([d_fwd(x2, W, y, bias=b)])
         r = Rows(V, 0, 0)
-        call("nast_log_softmax_fwd_f32", _p(y), r, _p(y), r, y.shape[0], V, 1.0 / temperature, _stream())
+        # the logits are read once for two floats per row (log-sum-exp, NLL); the log-probabilities are never written
         nll = torch.empty(x2.shape[0], device=x.device, dtype=F32)
-        call("nast_nll_gather_f32", _p(y), r, _p(tokens), _p(nll), y.shape[0], V, _stream())
-        ctx.save_for_backward(x2, W, y, tokens)
+        lse = torch.empty(x2.shape[0], device=x.device, dtype=F32)
+        call("nast_lse_nll_f32", _p(y), r, _p(tokens), _p(lse), _p(nll), y.shape[0], V, 1.0 / temperature, _stream())
+        ctx.save_for_backward(x2, W, y, tokens, lse)
         ctx.params = live(W, b)
         ctx.it, ctx.xshape = 1.0 / temperature, x.shape
         return nll.view(x.shape[:-1])
 
     @staticmethod
     def backward(ctx, g):
-        x2, W, y, tokens = ctx.saved_tensors
+        x2, W, y, tokens, lse = ctx.saved_tensors
         V = W.shape[0]
         g = _c(g).view(-1)
         r = Rows(V, 0, 0)
         gl = torch.empty_like(y)
-        call("nast_nll_log_softmax_bwd_f32", _p(g), _p(y), r, _p(tokens), _p(gl), r, y.shape[0], V, ctx.it, _stream())
+        call("nast_nll_logits_bwd_f32", _p(g), _p(y), r, _p(lse), _p(tokens), _p(gl), r, y.shape[0], V, ctx.it, _stream())
         (dW, db), (rW, rb) = grad_buffers(list(ctx.params))
         dx = torch.empty_like(x2)
         gemm([d_dgrad([gl], [W], dx)] + wgrad_descs(gl, x2, dW, db))
