@@ -333,7 +333,7 @@ def main():
             for i in range(warm):
                 fn(i)
             torch.cuda.synchronize()
-            lib.nast_prof_begin(0)      # every family: 1 GEMM, 2 vocabulary row kernels, 3 alignment DP, 4 small-M GEMM, 5 LSE alignment
+            lib.nast_prof_begin(0)      # every family: 1 GEMM, 2 vocabulary row kernels, 3 alignment DP, 4 small-M GEMM, 5 LSE alignment, 6 cluster decode
             for i in range(n):
                 fn(warm + i)
             torch.cuda.synchronize()
@@ -376,6 +376,11 @@ def main():
                                                        "launches": n4, "avg_launch_us": round(ms4 * 1e3 / max(n4, 1), 2)}
                     allf = (fl1 + fl4) / ((ms1 + ms4) * 1e-3) / 1e12
                     roofline["gemm_family_all"] = {"achieved": round(allf, 2), "frac": round(allf / PEAK_FP32_MFMA_TFLOPS, 4), "launches": n1 + n4}
+                ms6, fl6, n6 = family(6)      # the skip decode as one persistent launch (csrc/decode_cluster.hip): latency-bound by design
+                if ms6 > 0:
+                    roofline["decode_cluster_kernel"] = {"ms_per_decode": round(ms6 / max(n6, 1), 3), "achieved": round(fl6 / (ms6 * 1e-3) / 1e12, 2),
+                                                         "unit": "TFLOP/s", "launches": n6,
+                                                         "note": "32 steps x 26 dependent operations separated by cluster barriers; bound by the hand-off latency, not by MFMA"}
                 # the HBM-bound families next to it: algorithmic bytes / HIP-event time
                 hbm = {}
                 for kind, name in ((2, "vocab_row_kernels"), (3, "alignment_dp")):

@@ -380,7 +380,8 @@ int nast_multi_adam_f32(float* const* params, float* const* grads /* scaled in p
  * In-library kernel timing (HIP events on the caller's stream) for bench.py's roofline block.
  * nast_prof_begin(kind) arms timing of every subsequent launch of that kernel family (kind: 1 = tiled GEMM kernel,
  * work = FLOP; 2 = vocabulary row kernels, work = algorithmic bytes; 3 = alignment DP, work = bytes; 4 = small-M GEMM
- * kernel of the greedy decode, work = FLOP; 5 = the log-sum-exp alignment extension, work = bytes; 0 = all of them);
+ * kernel of the greedy decode, work = FLOP; 5 = the log-sum-exp alignment extension, work = bytes; 6 = the cluster decode
+ * kernel (one launch per decode), work = FLOP of its projections; 0 = all of them);
  * nast_prof_end() synchronises the events and reports the GEMM totals, nast_prof_get(kind) any family's.
  * Not graph-capture safe while armed.
  * ---------------------------------------------------------------------------------------------- */

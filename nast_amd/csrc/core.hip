@@ -21,7 +21,7 @@ extern "C" int nast_version(void) { return 100; }
 
 // ---- profiler: one (start, stop) event pair per armed launch, per kernel family -------------
 namespace {
-constexpr int NKIND = 6;       // 1 = tiled GEMM (work = FLOP), 2 = vocabulary row kernels (algorithmic bytes), 3 = alignment DP (bytes),
+constexpr int NKIND = 7;       // 1 = tiled GEMM (work = FLOP), 2 = vocabulary row kernels (algorithmic bytes), 3 = alignment DP (bytes),
                                // 4 = small-M GEMM of the greedy decode (FLOP), 5 = log-sum-exp alignment extension (bytes)
 struct Fam {
   std::vector<hipEvent_t> ev;   // pairs
@@ -77,7 +77,7 @@ void nast_prof_after(int kind, hipStream_t s, double work, const char* sig) {
 }
 
 extern "C" int nast_prof_begin(int kind) {
-  g_prof.mask = kind == 0 ? 0x3Eu : (1u << kind);   // 0 = every family
+  g_prof.mask = kind == 0 ? 0x7Eu : (1u << kind);   // 0 = every family
   for (int k = 0; k < NKIND; ++k) {
     Fam& f = g_prof.fam[k];
     for (hipEvent_t e : f.ev) g_prof.pool.push_back(e);

@@ -636,7 +636,12 @@ int nast_lp_decode_cluster_launch(const nast_lp_decode_args* A, const float* can
     nast_set_error("nast_lp_decode_f32(cluster): memset failed: %s", hipGetErrorString(hipGetLastError()));
     return NAST_ELAUNCH;
   }
+  nast_prof_before(6, s);
   hipLaunchKernelGGL(nast_lp_decode_cluster_kernel, dim3(NCLUSTER * NMEMBER), dim3(256), 0, s, F);
+  {   // profiling family 6: the whole decode as one launch; work = FLOP of its projections (6 d x d + 2 d x dff per layer, + wq)
+    const double per_row = 2.0 * (A->nlayers * (6.0 * CD * CD + 2.0 * CD * CFF) + (double)CD * CD);
+    nast_prof_after(6, s, per_row * A->B * A->L);
+  }
   if (steps_dev && nast_lp_steps_from_allpos_launch(A->allpos, A->origin_length, A->B, A->L, steps_dev, s) != 0) return NAST_ELAUNCH;
 #ifdef CLUSTER_STAMPS
   {
