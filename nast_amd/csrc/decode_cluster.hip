@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256, 2) void nast_lp_decode_cluster_kernel(const Cl
   __shared__ __attribute__((aligned(16))) float As[32 * LDX];          // activation tile [32 rows][256 k] (+4 pad)
   __shared__ __attribute__((aligned(16))) float red[4 * 32 * RLD];     // K-split partial sums of one output tile
   __shared__ Op ops[MAXOPS];
-  __shared__ float ln_s[2 * CD];                                       // LayerNorm scale | shift of the current operation
+  // LayerNorm scale | shift of the current operation: used before the MFMAs, `red` after them -- one piece of LDS, which keeps
+  // the workgroup under 49.4 KB, i.e. leaves room for THREE 36.9-KB workgroups of the tiled GEMM on the CU while the decode runs
+  float* const ln_s = red;
   __shared__ int now_s[4][MAXSPW];
   __shared__ int abort_s;
 
