@@ -34,15 +34,29 @@ void nast_prof_after(int kind, hipStream_t s, double work, const char* sig = nul
 bool nast_prof_shapes(int kind);   // true when per-signature timing is wanted (NAST_PROF_SHAPES set and the family armed)
 
 // ---- wave / block reductions (64-wide wavefronts) ------------------------------------------
+// Every lane gets the result.  (Round 3: DPP butterflies inside a row of 16 lanes -- quad_perm xor 1, xor 2, then
+// row_half_mirror and row_mirror, which pair quads / halves that already hold equal values -- and v_readlane across the four
+// rows, instead of the six ds_bpermute that `__shfl_xor` compiles to: no LDS-crossbar round trips in the row kernels.)
+template <int CTRL>
+__device__ __forceinline__ float nast_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float nast_lane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += nast_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += nast_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += nast_dpp<0x141>(v);     // row_half_mirror
+  v += nast_dpp<0x140>(v);     // row_mirror
+  return (nast_lane(v, 0) + nast_lane(v, 16)) + (nast_lane(v, 32) + nast_lane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, nast_dpp<0xB1>(v));
+  v = fmaxf(v, nast_dpp<0x4E>(v));
+  v = fmaxf(v, nast_dpp<0x141>(v));
+  v = fmaxf(v, nast_dpp<0x140>(v));
+  return fmaxf(fmaxf(nast_lane(v, 0), nast_lane(v, 16)), fmaxf(nast_lane(v, 32), nast_lane(v, 48)));
 }
 
 // Block-wide sum / max for blockDim.x == NT (multiple of 64); `red` is LDS scratch of NT/64 floats.
