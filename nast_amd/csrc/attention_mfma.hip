@@ -1072,6 +1072,132 @@ __global__ __launch_bounds__(256, 1) void nast_mha_bwd_long_kernel(const AttnArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Single query per sentence against a long key range (nq == 1, nk > 64): the greedy decode of a long-sentence model
+// (configs[4]: 128 positions, 16 heads of 64) asks for this 6 times per step, and the tile kernels above spend 41 us staging
+// 144-row images for one query row.  Here the work is a stream of K and V rows: one workgroup per (sentence, head), a row is
+// read by DK/4 consecutive lanes as one 16-byte piece each (4 rows per wavefront instruction at DK = 64), key j goes to lane group
+// j mod G (G = 1024 / DK groups in the workgroup), and every group keeps its own running (max, sum, weighted V row) -- the groups
+// never talk inside the key loop.  All CK rows a group will need of K and of V are requested before any arithmetic (one memory
+// round trip for up to G*CK keys); the partial softmaxes meet at the end: across the groups of a wavefront by shuffles, across
+// the four wavefronts through LDS.  No MFMA: 2*nk*DK multiply-adds per head is nothing next to 2*nk*DK*4 bytes.
+// ---------------------------------------------------------------------------------------------------------
+template <int LPR>
+__device__ __forceinline__ float lanes_sum(float v) {   // over the LPR (4 / 8 / 16) consecutive lanes that share a row: DPP, no LDS
+  v += nast_dpp<0xB1>(v);                     // quad_perm [1,0,3,2]
+  v += nast_dpp<0x4E>(v);                     // quad_perm [2,3,0,1]
+  if constexpr (LPR >= 8) v += nast_dpp<0x141>(v);   // row_half_mirror
+  if constexpr (LPR >= 16) v += nast_dpp<0x140>(v);  // row_mirror
+  return v;
+}
+
+template <int DK, int CK>
+__global__ __launch_bounds__(256) void nast_mha_fwd_q1_kernel(const AttnArgs P) {
+  constexpr int LPR = DK / 4, GW = 64 / LPR, G = 4 * GW;      // lanes per row, groups per wavefront / per workgroup
+  __shared__ float m_s[4], l_s[4];
+  __shared__ __attribute__((aligned(16))) float acc_s[4][DK];
+  const int bh = blockIdx.x, b = bh / P.h, head = bh % P.h;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane % LPR, g = wave * GW + lane / LPR;
+  const int nk = P.nk;
+  const float* __restrict__ Kg = P.k + b * P.k_bs + head * DK + 4 * r;
+  const float* __restrict__ Vg = P.v + b * P.v_bs + head * DK + 4 * r;
+  const uint8_t* __restrict__ mrow = P.mask != nullptr ? P.mask + b * P.mask_bs : nullptr;
+  const float4 q4 = *reinterpret_cast<const float4*>(P.q + b * P.q_bs + head * DK + 4 * r);
+  const float scale = P.scale;
+  float m = -INFINITY, l = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j0 = 0; j0 < nk; j0 += G * CK) {        // (uniform for the workgroup; one trip up to G*CK keys)
+    float4 kr[CK], vr[CK];
+    uint8_t mb[CK];
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {                 // unconditional loads of a clamped row: the waits sink to the first use
+      const int j = j0 + c * G + g, jc = j < nk ? j : nk - 1;
+      kr[c] = *reinterpret_cast<const float4*>(Kg + (int64_t)jc * P.ldk);
+      vr[c] = *reinterpret_cast<const float4*>(Vg + (int64_t)jc * P.ldv);
+      mb[c] = mrow != nullptr ? mrow[jc] : (uint8_t)0;
+    }
+    float sc[CK], mc = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CK; ++c) {
+      const int j = j0 + c * G + g;
+      float t = kr[c].x * q4.x + kr[c].y * q4.y + kr[c].z * q4.z + kr[c].w * q4.w;
+      t = lanes_sum<LPR>(t) * scale;
+      sc[c] = (j < nk && mb[c] == 0) ? t : -INFINITY;
+      mc = fmaxf(mc, sc[c]);
+    }
+    if (mc > -INFINITY) {                          // (else: nothing live in this chunk for this group)
+      const float mn = fmaxf(m, mc), corr = __expf(m - mn);     // m = -inf: corr = 0
+      l *= corr; acc.x *= corr; acc.y *= corr; acc.z *= corr; acc.w *= corr;
+#pragma unroll
+      for (int c = 0; c < CK; ++c) {
+        const float p = __expf(sc[c] - mn);        // dead key: exp(-inf) = 0
+        l += p;
+        acc.x = fmaf(p, vr[c].x, acc.x); acc.y = fmaf(p, vr[c].y, acc.y);
+        acc.z = fmaf(p, vr[c].z, acc.z); acc.w = fmaf(p, vr[c].w, acc.w);
+      }
+      m = mn;
+    }
+  }
+  // the groups of this wavefront meet: common maximum, rescaled sums (lanes with the same r hold the same channels)
+  float mw = m;
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+  const float w = m > -INFINITY ? __expf(m - mw) : 0.f;
+  l *= w; acc.x *= w; acc.y *= w; acc.z *= w; acc.w *= w;
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) {
+    l += __shfl_xor(l, o, 64);
+    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  if (lane < LPR) {
+    *reinterpret_cast<float4*>(&acc_s[wave][4 * r]) = acc;
+    if (lane == 0) { m_s[wave] = mw; l_s[wave] = l; }
+  }
+  __syncthreads();
+  if (threadIdx.x < LPR) {                          // the four wavefronts meet
+    const float M = fmaxf(fmaxf(m_s[0], m_s[1]), fmaxf(m_s[2], m_s[3]));
+    float lt = 0.f;
+    float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float wu = m_s[u] > -INFINITY ? __expf(m_s[u] - M) : 0.f;
+      const float4 a = *reinterpret_cast<const float4*>(&acc_s[u][4 * r]);
+      lt = fmaf(l_s[u], wu, lt);
+      o4.x = fmaf(a.x, wu, o4.x); o4.y = fmaf(a.y, wu, o4.y); o4.z = fmaf(a.z, wu, o4.z); o4.w = fmaf(a.w, wu, o4.w);
+    }
+    const float inv = 1.f / lt;                     // every key masked: 0 / 0 = NaN, like the reference's softmax over -inf
+    o4.x *= inv; o4.y *= inv; o4.z *= inv; o4.w *= inv;
+    if (!(lt > 0.f)) o4 = make_float4(NAN, NAN, NAN, NAN);
+    *reinterpret_cast<float4*>(P.out + b * P.o_bs + head * DK + 4 * r) = o4;
+    if (threadIdx.x == 0 && P.lse != nullptr) P.lse[(int64_t)bh * P.nq] = M + __logf(lt);
+  }
+}
+
+template <int DK>
+int launch_q1(const AttnArgs& A, hipStream_t s) {
+  constexpr int G = 1024 / DK;
+  const dim3 grid(A.BH), block(256);
+  if (A.nk <= 3 * G) hipLaunchKernelGGL((nast_mha_fwd_q1_kernel<DK, 3>), grid, block, 0, s, A);
+  else if (A.nk <= 6 * G) hipLaunchKernelGGL((nast_mha_fwd_q1_kernel<DK, 6>), grid, block, 0, s, A);
+  else hipLaunchKernelGGL((nast_mha_fwd_q1_kernel<DK, 9>), grid, block, 0, s, A);
+  return 0;
+}
+// nq == 1 on a padded batch with more than 64 keys (fewer: the wavefront kernel below is already one round trip)
+static int dispatch_q1(const AttnArgs& A, int dk, hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("NAST_ATTN_Q1"); return !e || atoi(e) != 0; }();   // A/B aid
+  if (!on || A.nq != 1 || A.q_off != nullptr || A.nk <= 64) return 1;
+  if ((A.ldk & 3) || (A.ldv & 3) || (A.k_bs & 3) || (A.v_bs & 3) || (A.q_bs & 3) || (A.o_bs & 3)) return 1;
+  if ((reinterpret_cast<uintptr_t>(A.q) | reinterpret_cast<uintptr_t>(A.k) | reinterpret_cast<uintptr_t>(A.v) | reinterpret_cast<uintptr_t>(A.out)) & 15) return 1;
+  switch (dk) {
+    case 16: return launch_q1<16>(A, s);
+    case 32: return launch_q1<32>(A, s);
+    case 64: return launch_q1<64>(A, s);
+  }
+  return 1;
+}
+
 template <int DK>
 int launch_long(const AttnArgs& A, bool bwd, hipStream_t s) {
   const dim3 grid(A.BH), block(256);
@@ -1138,6 +1264,7 @@ int nast_mha_fwd_mfma(const float* q, const float* k, const float* v, const uint
   A.q = q; A.k = k; A.v = v; A.mask = mask; A.out = out; A.lse = lse;
   A.BH = B * h; A.h = h; A.nq = nq; A.nk = nk; A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.ldo = ldo;
   A.q_bs = q_bs; A.k_bs = k_bs; A.v_bs = v_bs; A.o_bs = o_bs; A.mask_bs = mask_bs; A.mask_qs = mask_qs; A.scale = scale;
+  if (dispatch_q1(A, dk, s) == 0) return 0;
   if (nq > 64 || nk > 64) return dispatch_long(A, dk, false, s);
   const int nkt = (nk + 15) / 16;
   switch (dk) {

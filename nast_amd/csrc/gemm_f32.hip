@@ -511,8 +511,13 @@ struct SkinnyLaunch {
   int count;
 };
 
-__global__ __launch_bounds__(256) void nast_gemm_f32_skinny_kernel(const SkinnyLaunch P) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 32 * 33];
+// NW wavefronts share the K range of a tile.  NW = 16 (1024 threads) is for wide models at small batch (K, N >= 1024 and too few
+// tiles to fill the chip: configs[4]'s decode has 64 tiles per projection): a wavefront's K slice is then one or a few bursts,
+// so the launch costs about one memory round trip instead of K / 256 of them, and every SIMD of the chip holds a wavefront.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void nast_gemm_f32_skinny_kernel(const SkinnyLaunch P) {
+  constexpr int NT = NW * 64, EPT = 1024 / NT;      // threads, output elements per thread
+  __shared__ __attribute__((aligned(16))) float red[NW * 32 * 33];
   __shared__ float ln_gb[2 * 256];      // LayerNorm gamma | beta (K <= 256 when fused)
   // (An XCD-contiguous tile order -- XCD x gets the x-th eighth of the tile list, so that its L2 pulls only its share of A --
   // measured no change: 8.35 vs 8.34 ms per decode.)
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_skinny_kernel(const SkinnyL
   const float* __restrict__ Bp = D.B[0] + (int64_t)(bok ? brow : 0) * D.ldb;
   // K slice of this wavefront, in 16-wide groups
   const int ngroups = (K + 15) / 16;
-  const int gper = (ngroups + 3) / 4;
+  const int gper = (ngroups + NW - 1) / NW;
   const int g_lo = wave * gper;
   int g_hi = g_lo + gper;
   if (g_hi > ngroups) g_hi = ngroups;
@@ -542,15 +547,15 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_skinny_kernel(const SkinnyL
   // on the first operand round trip (activations written by the previous kernel come from the Infinity Cache), and every
   // later load that waits for its own round trip -- the LayerNorm scale / shift, the epilogue's bias and residual -- adds
   // 1.5 - 2 us on top.  gamma / beta go to LDS (one element per thread), bias / residual values to registers.
-  const bool fuse_ln = D.ln_gamma != nullptr;       // host guarantees K <= 256: one burst per wavefront
+  const bool fuse_ln = NW == 4 && D.ln_gamma != nullptr;       // host guarantees K <= 256 and NW = 4: one burst per wavefront
   if (fuse_ln && (int)threadIdx.x < K) {
     ln_gb[threadIdx.x] = D.ln_gamma[threadIdx.x];
     ln_gb[256 + threadIdx.x] = D.ln_beta[threadIdx.x];
   }
-  float pre_bias[4], pre_res[4];
+  float pre_bias[EPT], pre_res[EPT];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int idx = threadIdx.x + 256 * e;
+  for (int e = 0; e < EPT; ++e) {
+    const int idx = threadIdx.x + NT * e;
     const int gr = tm * 32 + (idx >> 5), gc = tn * 32 + (idx & 31);
     const bool ok = gr < M && gc < N;
     pre_bias[e] = (ok && D.bias) ? D.bias[gc] : 0.f;
@@ -626,12 +631,16 @@ __global__ __launch_bounds__(256) void nast_gemm_f32_skinny_kernel(const SkinnyL
   const float alpha = D.alpha;
   const int flags = D.flags;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int idx = threadIdx.x + 256 * e;        // 0..1023
+  for (int e = 0; e < EPT; ++e) {
+    const int idx = threadIdx.x + NT * e;         // 0..1023
     const int row = idx >> 5, col = idx & 31;
     const int gr = tm * 32 + row, gc = tn * 32 + col;
     if (gr >= M || gc >= N) continue;
     float v = red[row * 33 + col] + red[(32 + row) * 33 + col] + red[(64 + row) * 33 + col] + red[(96 + row) * 33 + col];
+#pragma unroll
+    for (int w4 = 4; w4 < NW; w4 += 4)
+      v += (red[(32 * w4 + row) * 33 + col] + red[(32 * w4 + 32 + row) * 33 + col]) +
+           (red[(32 * w4 + 64 + row) * 33 + col] + red[(32 * w4 + 96 + row) * 33 + col]);
     v *= alpha;
     v += pre_bias[e];
     const int64_t o = (int64_t)gr * D.ldc + gc;
@@ -664,7 +673,12 @@ static void launch_skinny(const nast_gemm_desc* descs, int count, hipStream_t st
   }
   for (int i = count; i <= NAST_GEMM_MAX_GROUP; ++i) P.tile_start[i] = start;
   if (start == 0) return;
-  hipLaunchKernelGGL(nast_gemm_f32_skinny_kernel, dim3(start), dim3(256), 0, stream, P);
+  // wide weights, few tiles: 16 wavefronts per tile (never with a fused LayerNorm, which needs K <= 256)
+  static const int wide_on = [] { const char* e = getenv("NAST_GEMM_SKINNY_WIDE"); return e ? atoi(e) : 1; }();
+  bool wide = wide_on != 0 && start <= 384;
+  for (int i = 0; i < count && wide; ++i) wide = descs[i].K >= 1024 && descs[i].N >= 1024 && descs[i].ln_gamma == nullptr;
+  if (wide) hipLaunchKernelGGL(nast_gemm_f32_skinny_kernel<16>, dim3(start), dim3(1024), 0, stream, P);
+  else hipLaunchKernelGGL(nast_gemm_f32_skinny_kernel<4>, dim3(start), dim3(256), 0, stream, P);
 }
 
 bool nast_gemm_bstat_eligible(const nast_gemm_desc& D);                                   // gemm_bstat.hip

@@ -115,6 +115,35 @@ def test_gemm_in_place_residual_with_long_k(ops):
     relclose(y2, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (40, 1024, 4096), (64, 4096, 1024), (7, 1056, 1040), (96, 3072, 1024)])
+def test_gemm_small_m_wide_model(ops, M, N, K):
+    """The small-M path with 16 wavefronts per 32x32 tile (K, N >= 1024 and at most 384 tiles: the decode of a d = 1024 model at a
+    small batch): bias, residual, ReLU, an in-place residual, a grouped launch -- against float64 on the CPU."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x, W, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = x.double() @ W.double().t()
+    xd, Wd, bd, rd = dev(x), dev(W), dev(b), dev(r)
+
+    def run(**kw):
+        y = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm([ops.d_fwd(xd, Wd, y, **kw)])
+        return y
+
+    relclose(run(), ref)
+    relclose(run(bias=bd, residual=rd), ref + b.double() + r.double())
+    relclose(run(bias=bd, relu=True), torch.relu(ref + b.double()))
+    y = rd.clone()
+    ops.gemm([ops.d_fwd(xd, Wd, y, bias=bd, residual=y)])
+    relclose(y, ref + b.double() + r.double())
+    if N * ((M + 31) // 32) * 3 <= 384 * 32:
+        Ws = [torch.randn(N, K, generator=g) / math.sqrt(K) for _ in range(3)]
+        Wds = [dev(w) for w in Ws]
+        ys = [torch.empty(M, N, device="cuda") for _ in range(3)]
+        ops.gemm([ops.d_fwd(xd, w, y_, bias=bd) for w, y_ in zip(Wds, ys)])
+        for w, y_ in zip(Ws, ys):
+            relclose(y_, x.double() @ w.double().t() + b.double())
+
+
 def test_gemm_relu_and_matmul_nn(ops):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(130, 48, generator=g)
@@ -191,6 +220,9 @@ def ref_attention(q, k, v, mask, h):
                                                 (3, 129, 129, 2, 64, "pad"), (2, 100, 130, 2, 32, "pad"), (2, 80, 80, 2, 16, "causal"),
                                                 (2, 144, 144, 1, 64, "none"), (2, 65, 129, 2, 64, "causal"), (2, 130, 40, 2, 64, "pad"),
                                                 (2, 150, 150, 1, 64, "pad"),
+                                                # one query, more than 64 keys: the streaming single-query kernel (decode of long sentences)
+                                                (5, 1, 129, 4, 64, "pad"), (3, 1, 65, 2, 64, "none"), (4, 1, 100, 2, 32, "pad"), (3, 1, 144, 2, 16, "pad"),
+                                                (70, 1, 97, 16, 64, "pad"),
                                                 # >= 1024 (sentence, head) items: the backward's split form (delta from dO * O)
                                                 (260, 33, 33, 4, 64, "pad"), (300, 20, 30, 4, 32, "causal"), (520, 12, 16, 2, 16, "pad"),
                                                 (600, 9, 11, 2, 8, "pad"), (1030, 40, 48, 1, 64, "none")])
@@ -214,6 +246,18 @@ def test_attention(ops, B, nq, nk, h, dk, kind):
     y = ops.attention(qg, kg, vg, dev(mask) if mask is not None else None, h)
     (y * dev(R)).sum().backward()
     relclose(y, yref); relclose(qg.grad, qr.grad); relclose(kg.grad, kr.grad); relclose(vg.grad, vr.grad)
+
+
+def test_attention_single_query_forward_beyond_tile_limits(ops):
+    """One query against 300 keys (more than any tile kernel holds): the streaming single-query kernel loops over the keys."""
+    g = torch.Generator().manual_seed(5)
+    B, nk, h, dk = 3, 300, 2, 64
+    q, k, v = torch.randn(B, 1, h * dk, generator=g), torch.randn(B, nk, h * dk, generator=g), torch.randn(B, nk, h * dk, generator=g)
+    lens = torch.tensor([300, 1, 177])
+    mask = (torch.arange(nk)[None] >= lens[:, None]).view(B, 1, 1, nk)
+    with torch.no_grad():
+        y = ops.attention(dev(q), dev(k), dev(v), dev(mask), h)
+    relclose(y, ref_attention(q, k, v, mask, h))
 
 
 @pytest.mark.parametrize("B,n,h,dk,holes", [(6, 33, 4, 64, False), (5, 48, 2, 32, False), (4, 33, 4, 64, True), (3, 20, 4, 16, True),
