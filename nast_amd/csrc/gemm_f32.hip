@@ -511,13 +511,8 @@ struct SkinnyLaunch {
   int count;
 };
 
-// NW wavefronts share the K range of a tile.  NW = 16 (1024 threads) is for wide models at small batch (K, N >= 1024 and too few
-// tiles to fill the chip: configs[4]'s decode has 64 tiles per projection): a wavefront's K slice is then one or a few bursts,
-// so the launch costs about one memory round trip instead of K / 256 of them, and every SIMD of the chip holds a wavefront.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void nast_gemm_f32_skinny_kernel(const SkinnyLaunch P) {
-  constexpr int NT = NW * 64, EPT = 1024 / NT;      // threads, output elements per thread
-  __shared__ __attribute__((aligned(16))) float red[NW * 32 * 33];
+__global__ __launch_bounds__(256) void nast_gemm_f32_skinny_kernel(const SkinnyLaunch P) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 32 * 33];
   __shared__ float ln_gb[2 * 256];      // LayerNorm gamma | beta (K <= 256 when fused)
   // (An XCD-contiguous tile order -- XCD x gets the x-th eighth of the tile list, so that its L2 pulls only its share of A --
   // measured no change: 8.35 vs 8.34 ms per decode.)
@@ -536,7 +531,7 @@ __global__ __launch_bounds__(NW * 64) void nast_gemm_f32_skinny_kernel(const Ski
   const float* __restrict__ Bp = D.B[0] + (int64_t)(bok ? brow : 0) * D.ldb;
   // K slice of this wavefront, in 16-wide groups
   const int ngroups = (K + 15) / 16;
-  const int gper = (ngroups + NW - 1) / NW;
+  const int gper = (ngroups + 3) / 4;
   const int g_lo = wave * gper;
   int g_hi = g_lo + gper;
   if (g_hi > ngroups) g_hi = ngroups;
@@ -547,15 +542,15 @@ __global__ __launch_bounds__(NW * 64) void nast_gemm_f32_skinny_kernel(const Ski
   // on the first operand round trip (activations written by the previous kernel come from the Infinity Cache), and every
   // later load that waits for its own round trip -- the LayerNorm scale / shift, the epilogue's bias and residual -- adds
   // 1.5 - 2 us on top.  gamma / beta go to LDS (one element per thread), bias / residual values to registers.
-  const bool fuse_ln = NW == 4 && D.ln_gamma != nullptr;       // host guarantees K <= 256 and NW = 4: one burst per wavefront
+  const bool fuse_ln = D.ln_gamma != nullptr;       // host guarantees K <= 256: one burst per wavefront
   if (fuse_ln && (int)threadIdx.x < K) {
     ln_gb[threadIdx.x] = D.ln_gamma[threadIdx.x];
     ln_gb[256 + threadIdx.x] = D.ln_beta[threadIdx.x];
   }
-  float pre_bias[EPT], pre_res[EPT];
+  float pre_bias[4], pre_res[4];
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int idx = threadIdx.x + NT * e;
+  for (int e = 0; e < 4; ++e) {
+    const int idx = threadIdx.x + 256 * e;
     const int gr = tm * 32 + (idx >> 5), gc = tn * 32 + (idx & 31);
     const bool ok = gr < M && gc < N;
     pre_bias[e] = (ok && D.bias) ? D.bias[gc] : 0.f;
@@ -631,16 +626,12 @@ __global__ __launch_bounds__(NW * 64) void nast_gemm_f32_skinny_kernel(const Ski
   const float alpha = D.alpha;
   const int flags = D.flags;
 #pragma unroll
-  for (int e = 0; e < EPT; ++e) {
-    const int idx = threadIdx.x + NT * e;         // 0..1023
+  for (int e = 0; e < 4; ++e) {
+    const int idx = threadIdx.x + 256 * e;        // 0..1023
     const int row = idx >> 5, col = idx & 31;
     const int gr = tm * 32 + row, gc = tn * 32 + col;
     if (gr >= M || gc >= N) continue;
     float v = red[row * 33 + col] + red[(32 + row) * 33 + col] + red[(64 + row) * 33 + col] + red[(96 + row) * 33 + col];
-#pragma unroll
-    for (int w4 = 4; w4 < NW; w4 += 4)
-      v += (red[(32 * w4 + row) * 33 + col] + red[(32 * w4 + 32 + row) * 33 + col]) +
-           (red[(32 * w4 + 64 + row) * 33 + col] + red[(32 * w4 + 96 + row) * 33 + col]);
     v *= alpha;
     v += pre_bias[e];
     const int64_t o = (int64_t)gr * D.ldc + gc;
@@ -651,34 +642,174 @@ __global__ __launch_bounds__(NW * 64) void nast_gemm_f32_skinny_kernel(const Ski
   }
 }
 
+// Small-M GEMM for WIDE models (K >= 512): 16x16 output tiles on v_mfma_f32_16x16x4_f32.  At M = 64 (configs[4]'s decode) the
+// 32x32 tiling above gives a projection of the d = 1024 model 64 workgroups -- a quarter of the chip's matrix pipes run 3.4 us
+// of MFMAs each while the rest idle, and 4 or 16 wavefronts per tile make no difference to that (measured: 13.5 / 12.4 us per
+// launch, weights hot or cold) -- where 16x16 tiles give it 256 (0.85 us of MFMAs per CU).  A wavefront owns a quarter of K and
+// fetches ALL of its slice up to K = 1024 in one round trip: lane (r = lane & 15, g = lane >> 4) holds row r's columns
+// 16 q + 4 g .. + 3 for MFMA steps 4 q .. 4 q + 3 (the same k permutation for both operands), i.e. the four lanes of a row read
+// 64 contiguous bytes.  With K <= 1024 the LayerNorm of the A rows is fused as in the 32x32 kernel (statistics over the lanes of
+// a row and the four wavefronts through LDS), which removes the separate LayerNorm launch in front of every projection.
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+template <bool LN>
+__global__ __launch_bounds__(256) void nast_gemm_f32_skinny16_kernel(const SkinnyLaunch P) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 17];
+  __shared__ __attribute__((aligned(16))) float ln_gb[LN ? 2 * 1024 : 4];
+  __shared__ float ln_red[2 * 4 * 16];
+  const int bid = blockIdx.x;
+  int gi = 0;
+  while (gi + 1 < P.count && bid >= P.tile_start[gi + 1]) ++gi;
+  const nast_gemm_desc& D = P.d[gi];
+  const int local = bid - P.tile_start[gi];
+  const int tn = local % P.tiles_n[gi], tm = local / P.tiles_n[gi];
+  const int M = D.M, N = D.N, K = D.K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int arow = tm * 16 + r, brow = tn * 16 + r;
+  const float* __restrict__ Ap = D.A[0] + (int64_t)(arow < M ? arow : M - 1) * D.lda + 4 * g;
+  const float* __restrict__ Bp = D.B[0] + (int64_t)(brow < N ? brow : N - 1) * D.ldb + 4 * g;
+  const int ngroups = K / 16;                       // host: K % 16 == 0
+  const int gper = (ngroups + 3) / 4;
+  const int q_lo = wave * gper;
+  const int q_hi = q_lo + gper < ngroups ? q_lo + gper : ngroups;
+  // epilogue operands of this thread's output element, requested with everything else
+  const int orow = tm * 16 + ((int)threadIdx.x >> 4), ocol = tn * 16 + ((int)threadIdx.x & 15);
+  const bool ook = orow < M && ocol < N;
+  const float pre_bias = (ook && D.bias) ? D.bias[ocol] : 0.f;
+  const float pre_res = (ook && D.residual) ? D.residual[(int64_t)orow * D.ldc + ocol] : 0.f;
+  const bool fuse_ln = LN && D.ln_gamma != nullptr; // (uniform for the workgroup)  host: K <= 1024, one trip of the loop below
+  if constexpr (LN) {
+    if (fuse_ln) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = (int)threadIdx.x + 256 * e;
+        if (k < K) { ln_gb[k] = D.ln_gamma[k]; ln_gb[1024 + k] = D.ln_beta[k]; }
+      }
+    }
+  }
+  constexpr int CH = 16;                            // 16-wide k groups per round trip: 256 k per wavefront
+  f32x4g acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int q0 = q_lo; q0 < q_hi || (fuse_ln && q0 == q_lo); q0 += CH) {
+    float4 fa[CH], fb[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {                  // unconditional loads of a clamped group; the spare ones are zeroed below
+      const int q = q0 + c < q_hi ? q0 + c : (q_hi > q_lo ? q_hi - 1 : 0);
+      fa[c] = *reinterpret_cast<const float4*>(Ap + 16 * q);
+      fb[c] = *reinterpret_cast<const float4*>(Bp + 16 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);              // every load is in flight before the first MFMA (else the scheduler trickles them)
+    if (fuse_ln) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (q0 + c < q_hi) s1 += (fa[c].x + fa[c].y) + (fa[c].z + fa[c].w);
+      s1 += __shfl_xor(s1, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      if (g == 0) ln_red[wave * 16 + r] = s1;
+      __syncthreads();
+      const float mu = ((ln_red[r] + ln_red[16 + r]) + (ln_red[32 + r] + ln_red[48 + r])) / K;
+      float s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (q0 + c < q_hi) {
+          const float a = fa[c].x - mu, b = fa[c].y - mu, cc = fa[c].z - mu, d = fa[c].w - mu;
+          s2 += (a * a + b * b) + (cc * cc + d * d);
+        }
+      s2 += __shfl_xor(s2, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (g == 0) ln_red[64 + wave * 16 + r] = s2;
+      __syncthreads();
+      const float rs = rsqrtf(((ln_red[64 + r] + ln_red[80 + r]) + (ln_red[96 + r] + ln_red[112 + r])) / K + 1e-6f);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int k = 16 * (q0 + c < q_hi ? q0 + c : 0) + 4 * g;
+        const float4 ga = *reinterpret_cast<const float4*>(&ln_gb[k]);
+        const float4 be = *reinterpret_cast<const float4*>(&ln_gb[1024 + k]);
+        fa[c].x = (fa[c].x - mu) * rs * ga.x + be.x; fa[c].y = (fa[c].y - mu) * rs * ga.y + be.y;
+        fa[c].z = (fa[c].z - mu) * rs * ga.z + be.z; fa[c].w = (fa[c].w - mu) * rs * ga.w + be.w;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (q0 + c >= q_hi) fa[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c & 1) {
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb[c].x, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb[c].y, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].z, fb[c].z, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].w, fb[c].w, acc1, 0, 0, 0);
+      } else {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].x, fb[c].x, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].y, fb[c].y, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].z, fb[c].z, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c].w, fb[c].w, acc0, 0, 0, 0);
+      }
+    }
+  }
+  // accumulator layout: register e of lane (r, g) is C[row 4 g + e][col r]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[(wave * 16 + 4 * g + e) * 17 + r] = acc0[e] + acc1[e];
+  __syncthreads();
+  if (ook) {
+    const int row = (int)threadIdx.x >> 4, col = (int)threadIdx.x & 15;
+    float v = (red[row * 17 + col] + red[(16 + row) * 17 + col]) + (red[(32 + row) * 17 + col] + red[(48 + row) * 17 + col]);
+    v = v * D.alpha + pre_bias + pre_res;
+    if (D.flags & NAST_GEMM_RELU) v = fmaxf(v, 0.f);
+    const int64_t o = (int64_t)orow * D.ldc + ocol;
+    if (D.flags & NAST_GEMM_ACCUM) D.C[o] += v;
+    else D.C[o] = v;
+  }
+}
+
+// which small-M kernel: 16x16 tiles when the model is wide (every K >= 512, a multiple of 16) and the 32x32 tiling would leave
+// the chip under two tiles per CU, or when a LayerNorm over 256 < K <= 1024 is to be fused (only the 16x16 kernel can)
+static bool skinny16_able(const nast_gemm_desc* descs, int count) {
+  for (int i = 0; i < count; ++i)
+    if (descs[i].K < 512 || (descs[i].K & 15) || (descs[i].ln_gamma && descs[i].K > 1024)) return false;
+  return true;
+}
+static bool skinny_wide_ln(const nast_gemm_desc* descs, int count) {
+  for (int i = 0; i < count; ++i)
+    if (descs[i].ln_gamma && descs[i].K > 256) return true;
+  return false;
+}
+static bool skinny16_wanted(const nast_gemm_desc* descs, int count) {
+  static const bool on = [] { const char* e = getenv("NAST_GEMM_SKINNY16"); return !e || atoi(e) != 0; }();   // A/B aid
+  if (!skinny16_able(descs, count)) return false;
+  int tiles32 = 0;
+  for (int i = 0; i < count; ++i) tiles32 += ((descs[i].M + 31) / 32) * ((descs[i].N + 31) / 32);
+  return skinny_wide_ln(descs, count) || (on && tiles32 <= 512);
+}
+
 static bool skinny_ok(const nast_gemm_desc* descs, int count) {
   for (int i = 0; i < count; ++i) {
     const nast_gemm_desc& D = descs[i];
     if (D.M > 1024 || D.transA != 0 || D.transB == 0 || D.nsrc != 1 || D.relu_src || D.colsum || (D.flags & NAST_GEMM_ATOMIC)) return false;
-    if (D.ln_gamma && (D.K > 256 || !D.ln_beta)) return false;
+    if (D.ln_gamma && !D.ln_beta) return false;
     if ((D.lda & 3) || (D.ldb & 3) || (reinterpret_cast<uintptr_t>(D.A[0]) & 15) || (reinterpret_cast<uintptr_t>(D.B[0]) & 15)) return false;
   }
+  // a LayerNorm over more than 256 columns can only be fused by the 16x16 kernel, which then takes the whole group
+  if (skinny_wide_ln(descs, count) && !skinny16_able(descs, count)) return false;
   return true;
 }
 
 static void launch_skinny(const nast_gemm_desc* descs, int count, hipStream_t stream) {
   SkinnyLaunch P;
   P.count = count;
+  const bool t16 = skinny16_wanted(descs, count);
+  const int T = t16 ? 16 : 32;
   int start = 0;
+  bool any_ln = false;
   for (int i = 0; i < count; ++i) {
     P.d[i] = descs[i];
-    P.tiles_n[i] = (descs[i].N + 31) / 32;
+    P.tiles_n[i] = (descs[i].N + T - 1) / T;
     P.tile_start[i] = start;
-    start += P.tiles_n[i] * ((descs[i].M + 31) / 32);
+    start += P.tiles_n[i] * ((descs[i].M + T - 1) / T);
+    any_ln = any_ln || descs[i].ln_gamma != nullptr;
   }
   for (int i = count; i <= NAST_GEMM_MAX_GROUP; ++i) P.tile_start[i] = start;
   if (start == 0) return;
-  // wide weights, few tiles: 16 wavefronts per tile (never with a fused LayerNorm, which needs K <= 256)
-  static const int wide_on = [] { const char* e = getenv("NAST_GEMM_SKINNY_WIDE"); return e ? atoi(e) : 1; }();
-  bool wide = wide_on != 0 && start <= 384;
-  for (int i = 0; i < count && wide; ++i) wide = descs[i].K >= 1024 && descs[i].N >= 1024 && descs[i].ln_gamma == nullptr;
-  if (wide) hipLaunchKernelGGL(nast_gemm_f32_skinny_kernel<16>, dim3(start), dim3(1024), 0, stream, P);
-  else hipLaunchKernelGGL(nast_gemm_f32_skinny_kernel<4>, dim3(start), dim3(256), 0, stream, P);
+  if (!t16) hipLaunchKernelGGL(nast_gemm_f32_skinny_kernel, dim3(start), dim3(256), 0, stream, P);
+  else if (any_ln) hipLaunchKernelGGL(nast_gemm_f32_skinny16_kernel<true>, dim3(start), dim3(256), 0, stream, P);
+  else hipLaunchKernelGGL(nast_gemm_f32_skinny16_kernel<false>, dim3(start), dim3(256), 0, stream, P);
 }
 
 bool nast_gemm_bstat_eligible(const nast_gemm_desc& D);                                   // gemm_bstat.hip
@@ -874,7 +1005,7 @@ extern "C" int nast_gemm_f32(const nast_gemm_desc* descs, int count, void* strea
   }
   const bool skinny = skinny_ok(descs, count);
   for (int i = 0; i < count; ++i)
-    NAST_REQUIRE(descs[i].ln_gamma == nullptr || skinny, "nast_gemm_f32[%d]: fused LayerNorm needs the small-M path (M<=1024, K<=256, x W^T)", i);
+    NAST_REQUIRE(descs[i].ln_gamma == nullptr || skinny, "nast_gemm_f32[%d]: fused LayerNorm needs the small-M path (M<=1024, x W^T, K<=256 or K<=1024 with K%%16==0)", i);
   auto signature = [&](const char* head, const nast_gemm_desc* ds, int n) {
     std::string sig = head;
     for (int i = 0; i < n; ++i) {

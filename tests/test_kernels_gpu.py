@@ -115,18 +115,22 @@ def test_gemm_in_place_residual_with_long_k(ops):
     relclose(y2, ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (40, 1024, 4096), (64, 4096, 1024), (7, 1056, 1040), (96, 3072, 1024)])
+@pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (40, 1024, 4096), (64, 4096, 1024), (7, 1056, 1040), (96, 3072, 1024), (130, 520, 512)])
 def test_gemm_small_m_wide_model(ops, M, N, K):
-    """The small-M path with 16 wavefronts per 32x32 tile (K, N >= 1024 and at most 384 tiles: the decode of a d = 1024 model at a
-    small batch): bias, residual, ReLU, an in-place residual, a grouped launch -- against float64 on the CPU."""
+    """The small-M path's 16x16-tile kernel (every K >= 512 and a multiple of 16, at most 512 tiles of 32x32: the decode of a
+    d = 1024 model at a small batch): bias, residual, ReLU, an in-place residual, a grouped launch, and a LayerNorm of the A rows
+    fused into the product (K <= 1024) -- against float64 on the CPU."""
     g = torch.Generator().manual_seed(M + N + K)
     x, W, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
     ref = x.double() @ W.double().t()
     xd, Wd, bd, rd = dev(x), dev(W), dev(b), dev(r)
 
-    def run(**kw):
+    def run(ln=None, **kw):
         y = torch.full((M, N), float("nan"), device="cuda")
-        ops.gemm([ops.d_fwd(xd, Wd, y, **kw)])
+        d = ops.d_fwd(xd, Wd, y, **kw)
+        if ln is not None:
+            d.ln_gamma, d.ln_beta = ln[0].data_ptr(), ln[1].data_ptr()
+        ops.gemm([d])
         return y
 
     relclose(run(), ref)
@@ -135,13 +139,19 @@ def test_gemm_small_m_wide_model(ops, M, N, K):
     y = rd.clone()
     ops.gemm([ops.d_fwd(xd, Wd, y, bias=bd, residual=y)])
     relclose(y, ref + b.double() + r.double())
-    if N * ((M + 31) // 32) * 3 <= 384 * 32:
+    if N * ((M + 31) // 32) * 3 <= 512 * 32:
         Ws = [torch.randn(N, K, generator=g) / math.sqrt(K) for _ in range(3)]
         Wds = [dev(w) for w in Ws]
         ys = [torch.empty(M, N, device="cuda") for _ in range(3)]
         ops.gemm([ops.d_fwd(xd, w, y_, bias=bd) for w, y_ in zip(Wds, ys)])
         for w, y_ in zip(Ws, ys):
             relclose(y_, x.double() @ w.double().t() + b.double())
+    if K <= 1024 and K % 16 == 0:
+        gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
+        xs = x * 3 + 0.5
+        xd = dev(xs)
+        xn = torch.nn.functional.layer_norm(xs.double(), (K,), gam.double(), bet.double(), 1e-6)
+        relclose(run(ln=(dev(gam), dev(bet)), bias=bd, residual=rd), xn @ W.double().t() + b.double() + r.double())
 
 
 def test_gemm_relu_and_matmul_nn(ops):
