@@ -127,9 +127,12 @@ static int lp_decode_impl(const nast_lp_decode_args* A, float* workspace, int* s
   Ws w = carve(workspace, B, S1, d, dff, L, nl, h);
   const int NC = S1 + 5;
   const float scale = 1.0f / sqrtf((float)(d / h));
-  // LayerNorm inside the projection that consumes it: the small-M GEMM's 32x32 kernel up to 256 columns, its 16x16 kernel
-  // (wide models at a small batch) up to 1024
-  const bool fuse_ln = (B <= 1024 && d <= 256 && (d & 3) == 0) || (B <= 256 && d >= 512 && d <= 1024 && (d & 15) == 0);
+  // LayerNorm inside the projection that consumes it: the small-M GEMM's 32x32 kernel up to 256 columns.  Its 16x16 kernel
+  // (wide models at a small batch) can fuse up to 1024 columns, but measured no better than the separate launch (19.0 us
+  // against 4.8 + 11.4 per projection, configs[4] step 173 against 171.5 ms): every 16-column tile repeats the row statistics
+  // and holds both operands in registers across two barriers.  Off unless NAST_DECODE_WIDE_LN=1.
+  static const bool wide_ln = [] { const char* e = getenv("NAST_DECODE_WIDE_LN"); return e && atoi(e) != 0; }();
+  const bool fuse_ln = (B <= 1024 && d <= 256 && (d & 3) == 0) || (wide_ln && B <= 256 && d >= 512 && d <= 1024 && (d & 15) == 0);
 
   // one kernel for the whole loop when the model has the shape it is built for (decode_fused.hip); else step by step
   const bool fused = nast_lp_decode_fused_eligible(A) && (reinterpret_cast<uintptr_t>(A->eos) & 15) == 0;
