@@ -401,12 +401,15 @@ def main():
                     if "nast_gemm_f32_kernel" in t:
                         roofline["traffic"] = round(t["nast_gemm_f32_kernel"]["bytes_per_launch"])
                         roofline["traffic_unit"] = f"bytes per launch, PMC passes recorded in profiles/{os.path.basename(tpath)[:-5]}.txt"
-                    # the same launches as `achieved` counts: all four row kernels AND the NLL gather
-                    keys = ("nast_log_softmax_fwd_rr_kernel", "nast_softmax_bwd_rr_kernel", "nast_nll_log_softmax_bwd_kernel",
-                            "nast_gumbel_softmax_fwd_rr_kernel", "nast_nll_gather_kernel")
+                    # the same launches as `achieved` counts: every V-wide row kernel of the step (the PMC passes ran 5 f_steps:
+                    # tools/collect_profiles.sh, 2 warm-up + 3), per step and then per launch of the roofline pass
+                    keys = ("nast_lse_nll_kernel", "nast_nll_logits_bwd_kernel", "nast_softmax_bwd_rr_kernel", "nast_gumbel_softmax_fwd_rr_kernel",
+                            "nast_log_softmax_fwd_rr_kernel", "nast_nll_log_softmax_bwd_kernel", "nast_nll_gather_kernel")
                     fams = [t[k] for k in keys if k in t]
                     if fams and "vocab_row_kernels" in hbm:
-                        hbm["vocab_row_kernels"]["traffic"] = round(sum(x["bytes_per_launch"] * x["launches"] for x in fams) / sum(x["launches"] for x in fams))
+                        per_step = sum(x["bytes_per_launch"] * x["launches"] for x in fams) / 5.0
+                        hbm["vocab_row_kernels"]["traffic"] = round(per_step / (hbm["vocab_row_kernels"]["launches"] / n_roof))
+                        hbm["vocab_row_kernels"]["traffic_per_step"] = round(per_step)
         except Exception as e:      # noqa: BLE001  (the headline line is printed regardless)
             import traceback
             traceback.print_exc(file=sys.stderr)
