@@ -55,7 +55,8 @@ typedef struct nast_gemm_desc {
   float* colsum;                     /* [M] or NULL: with transA=1, colsum[m] (+)= sum_k op(A[0])[m,k]  (bias grad) */
   const float* ln_gamma;             /* [K] or NULL: op(A) rows are LayerNorm-ed on the fly (eps 1e-6) before the   */
   const float* ln_beta;              /* product (pre-LN sublayers, transformer.py:324-330). Small-M path only:      */
-                                     /* needs M <= 1024, K <= 256, transA=0, transB=1, else NAST_EINVAL.             */
+                                     /* needs M <= 1024, transA=0, transB=1 and K <= 256, or K <= 1024 with every     */
+                                     /* problem of the launch at K >= 512, K % 16 == 0; else NAST_EINVAL.            */
   int32_t M, N, K;
   int32_t lda, ldb, ldc;
   int32_t transA, transB;
