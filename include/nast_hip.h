@@ -234,6 +234,11 @@ int nast_align_lse_bwd_f32(const float* cost0, const float* cost, const int64_t*
 int nast_pack_index_i64(const int64_t* lengths, int B, int width, int total, int rows, int64_t* off, int32_t* off32,
                         int32_t* len32, int64_t* b_of, int64_t* pos, int64_t* idx, int64_t* idx_p, int* bad, void* stream);
 
+/* Key-padding mask of a ragged batch, one launch: mask[b][j] = j < extra ? 0 : (j - extra >= lengths[b]) for j < extra + width,
+ * one byte per element (1 = masked).  Replaces the arange / compare / zeros / cat of transformer.py:56-61, :135-139, :459-461
+ * (the reference builds the same mask from the same lengths).  lengths int64 [B].                                     */
+int nast_pad_mask_u8(const int64_t* lengths, uint8_t* mask, int B, int width, int extra, void* stream);
+
 /* Rows between the padded [B * width, d] layout and the packed one (ops.pack_rows / ops.unpack_rows and their backward
  * passes) -- no counterpart in the reference (see nast_pack_index_i64).  Both are gathers, one launch, no zero-fill:
  *   gather:  y[r] = x[idx[r]] for r < n_idx, zeros for n_idx <= r < rows_out   (x, y: row pitches ldx, ldy >= d)

@@ -70,6 +70,7 @@ SIGNATURES = {
     "nast_align_lse_fwd_f32": [c_fp] * 4 + [_f, c_fp, c_fp, _i, _i, _i, c_fp],
     "nast_align_lse_bwd_f32": [c_fp] * 4 + [_f] + [c_fp] * 5 + [_i, _i, _i, c_fp],
     "nast_pack_index_i64": [c_fp, _i, _i, _i, _i] + [c_fp] * 8 + [c_fp],
+    "nast_pad_mask_u8": [c_fp, c_fp, _i, _i, _i, c_fp],
     "nast_rows_gather_f32": [c_fp, _i64, c_fp, _i, _i, _i, c_fp, _i64, c_fp],
     "nast_rows_unpack_f32": [c_fp, _i64, _i, c_fp, c_fp, _i, _i, _i, c_fp, _i64, c_fp],
     "nast_noise_i64": [c_fp, c_fp, _i, _i, _i, c_fp, _d, c_fp, c_fp, _d, c_fp, c_fp, c_fp, _d, _d, _i64, _i64, _i64, _i, _i, c_fp, c_fp, c_fp],

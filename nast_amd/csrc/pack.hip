@@ -128,6 +128,28 @@ static bool rows_vec_ok(const void* a, const void* b, int64_t lda, int64_t ldb, 
   return (d & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0;
 }
 
+// Key-padding mask of a ragged batch in one launch (the torch formulation is arange, compare, zeros, cat: four):
+// mask[b][j] = j < extra ? 0 : (j - extra >= lengths[b]), one byte per element (torch.bool storage).
+__global__ __launch_bounds__(256) void nast_pad_mask_kernel(const int64_t* __restrict__ lengths, uint8_t* __restrict__ mask, int B, int cols,
+                                                           int extra) {
+  const int64_t n = (int64_t)B * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / cols), j = (int)(i % cols);
+    mask[i] = (j >= extra && (int64_t)(j - extra) >= lengths[b]) ? 1 : 0;
+  }
+}
+
+extern "C" int nast_pad_mask_u8(const int64_t* lengths, uint8_t* mask, int B, int width, int extra, void* stream) {
+  NAST_REQUIRE(B >= 0 && width >= 0 && extra >= 0, "nast_pad_mask_u8: negative sizes");
+  const int64_t n = (int64_t)B * (width + extra);
+  if (n == 0) return NAST_OK;
+  NAST_REQUIRE(lengths && mask, "nast_pad_mask_u8: NULL pointer");
+  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(nast_pad_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lengths, mask, B, width + extra, extra);
+  NAST_CHECK_LAUNCH("nast_pad_mask_u8");
+  return NAST_OK;
+}
+
 extern "C" int nast_rows_gather_f32(const float* x, int64_t ldx, const int64_t* idx, int n_idx, int rows_out, int d, float* y,
                                     int64_t ldy, void* stream) {
   NAST_REQUIRE(n_idx >= 0 && rows_out >= n_idx && d >= 1 && ldx >= d && ldy >= d, "nast_rows_gather_f32: bad sizes n_idx=%d rows_out=%d d=%d", n_idx, rows_out, d);

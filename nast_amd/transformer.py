@@ -79,9 +79,13 @@ def LayerNorm(embedding_dim, eps=1e-6):
 def _pad_mask(lengths, width, extra):
     """[B,1,1,extra+width] bool, True = masked (transformer.py:56-61, :135-139, :459-461)."""
     B = lengths.shape[0]
-    m = torch.arange(width, device=lengths.device).unsqueeze(0) >= lengths.unsqueeze(-1)
-    if extra:
-        m = torch.cat((torch.zeros(B, extra, dtype=torch.bool, device=lengths.device), m), 1)
+    if lengths.is_cuda and lengths.dtype == torch.int64:
+        m = torch.empty(B, extra + width, dtype=torch.bool, device=lengths.device)      # one launch instead of four
+        ops.call("nast_pad_mask_u8", lengths.contiguous().data_ptr(), m.data_ptr(), B, int(width), int(extra), ops._stream())
+    else:
+        m = torch.arange(width, device=lengths.device).unsqueeze(0) >= lengths.unsqueeze(-1)
+        if extra:
+            m = torch.cat((torch.zeros(B, extra, dtype=torch.bool, device=lengths.device), m), 1)
     m = m.view(B, 1, 1, extra + width)
     m.nast_lengths = (lengths, extra)          # lets Encoder / Decoder run on packed rows (ops.packed_of)
     return m

@@ -790,3 +790,17 @@ def test_pack_index_kernel_equals_torch_maps(ops, B, width, zero_frac):
     with pytest.raises(_lib.NastHipError):
         ops.check_packed()
     ops.check_packed()                                           # the flag was reset
+
+
+@pytest.mark.parametrize("B,width,extra", [(1, 1, 0), (7, 9, 1), (513, 33, 1), (64, 129, 2), (300, 17, 0)])
+def test_pad_mask_kernel_equals_torch_formulation(ops, B, width, extra):
+    """transformer._pad_mask through nast_pad_mask_u8 (one launch) against arange / compare / zeros / cat, lengths from 0 to
+    beyond the width."""
+    from nast_amd import transformer as tf
+    g = torch.Generator().manual_seed(B + width)
+    lengths = torch.randint(0, width + 3, (B,), generator=g)
+    got = tf._pad_mask(lengths.cuda(), width, extra)
+    ref = tf._pad_mask(lengths, width, extra)                  # CPU tensors take the torch formulation
+    assert got.dtype == torch.bool and got.shape == (B, 1, 1, extra + width) and got.is_contiguous()
+    assert torch.equal(got.cpu(), ref)
+    assert got.nast_lengths[1] == extra
